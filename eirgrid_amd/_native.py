@@ -1,0 +1,133 @@
+"""ctypes binding of libeirgrid_hip.so (the C ABI declared in include/eirgrid_hip.h).
+
+The library is built in-tree (eirgrid_amd/libeirgrid_hip.so) by `eirgrid_amd.build.build()`; importing this module
+fails loudly if it is missing — there is no Python or CPU implementation to fall back to.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+YEARS, N_ACTIONS, N_DEFICIT, N_COUNTS, N_TYPES = 26, 61, 15, 21, 15
+GRID, CELLS, YEARLY_FIELDS = 51, 2601, 21
+MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 1024, 1024, 2048, 1024, 1024
+STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + 2 * YEARS * N_DEFICIT
+
+EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeirgrid_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class EgWorld(C.Structure):
+    _fields_ = [("n_settlements", C.c_int32), ("settlement_x", _dp), ("settlement_y", _dp), ("settlement_pop", _u32p),
+                ("n_existing", C.c_int32), ("existing_x", _dp), ("existing_y", _dp), ("existing_type", _i32p),
+                ("existing_capacity_mw", _dp), ("n_coast", C.c_int32), ("coast_x", _dp), ("coast_y", _dp),
+                ("existing_operational_at_start", C.c_int32)]
+
+
+class EgOpts(C.Structure):
+    _fields_ = [("enable_energy_sales", C.c_int32), ("enable_construction_delays", C.c_int32), ("write_yearly", C.c_int32)]
+
+
+class EgPolicySnapshot(C.Structure):
+    _fields_ = [("weights", _dp), ("deficit_weights", _dp), ("count_weights", _dp),
+                ("learning_rate", C.c_double), ("exploration_rate", C.c_double),
+                ("iterations_without_improvement", C.c_uint32), ("has_best", C.c_int32),
+                ("best_metrics", C.c_double * 4),
+                ("best_count", _i32p), ("best_actions", _u8p), ("best_deficit_count", _i32p), ("best_deficit_actions", _u8p)]
+
+
+class EgEpisodeOut(C.Structure):
+    _fields_ = [("metrics", _dp), ("yearly", _dp), ("status", _i32p), ("n_run", _i32p), ("n_def", _i32p), ("n_act", _i32p),
+                ("run_log", _u8p), ("def_log", _u8p), ("act_log", _u8p), ("n_gens", _i32p), ("gen_cell", _u16p),
+                ("gen_pack", _u16p), ("n_offsets", _i32p), ("off_pack", _u16p), ("n_draws", _u64p), ("bytes_moved", _dp)]
+
+
+# every symbol include/eirgrid_hip.h declares
+EXPORTS = [
+    "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
+    "eg_rollout_launch", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_place",
+    "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
+    "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
+    "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  eirgrid_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.eg_last_error.restype = C.c_char_p
+    L.eg_device_count.restype = C.c_int32
+    L.eg_create.restype = C.c_void_p
+    L.eg_create.argtypes = [C.c_int32, C.POINTER(EgWorld)]
+    L.eg_destroy.argtypes = [C.c_void_p]
+    L.eg_rollout_batch.restype = C.c_int32
+    L.eg_rollout_batch.argtypes = [C.c_void_p, C.POINTER(EgPolicySnapshot), C.POINTER(EgOpts), C.c_uint64, C.c_uint64,
+                                   C.c_uint32, _u8p, C.POINTER(EgEpisodeOut)]
+    L.eg_upload_snapshot.restype = C.c_int32
+    L.eg_upload_snapshot.argtypes = [C.c_void_p, C.POINTER(EgPolicySnapshot), C.POINTER(EgOpts)]
+    L.eg_rollout_launch.restype = C.c_int32
+    L.eg_rollout_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, _u8p]
+    L.eg_sync.restype = C.c_int32
+    L.eg_sync.argtypes = [C.c_void_p]
+    L.eg_fetch.restype = C.c_int32
+    L.eg_fetch.argtypes = [C.c_void_p, C.POINTER(EgEpisodeOut)]
+    L.eg_timing_reset.restype = C.c_int32
+    L.eg_timing_reset.argtypes = [C.c_void_p]
+    L.eg_timing_read.restype = C.c_int32
+    L.eg_timing_read.argtypes = [C.c_void_p, _dp, _i32p]
+    L.eg_update_stats.restype = C.c_int32
+    L.eg_update_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.eg_place.restype = C.c_int32
+    L.eg_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u16p, C.c_int32, _i32p, _dp]
+    L.eg_host_tables_create.restype = C.c_void_p
+    L.eg_host_tables_create.argtypes = [C.POINTER(EgWorld)]
+    L.eg_host_tables_free.argtypes = [C.c_void_p]
+    L.eg_host_tables_f64.restype = C.c_int32
+    L.eg_host_tables_f64.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_dp), C.POINTER(C.c_int64)]
+    L.eg_host_tables_i32.restype = C.c_int32
+    L.eg_host_tables_i32.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(_i32p), C.POINTER(C.c_int64)]
+    L.eg_policy_new.restype = C.c_void_p
+    L.eg_policy_free.argtypes = [C.c_void_p]
+    L.eg_policy_snapshot_view.restype = C.c_int32
+    L.eg_policy_snapshot_view.argtypes = [C.c_void_p, C.POINTER(EgPolicySnapshot)]
+    L.eg_policy_get_tables.restype = C.c_int32
+    L.eg_policy_get_tables.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.eg_policy_set_tables.restype = C.c_int32
+    L.eg_policy_set_tables.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.eg_policy_get_scalar.restype = C.c_double
+    L.eg_policy_get_scalar.argtypes = [C.c_void_p, C.c_int32]
+    L.eg_policy_set_scalar.restype = C.c_int32
+    L.eg_policy_set_scalar.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+    L.eg_policy_get_list.restype = C.c_int32
+    L.eg_policy_get_list.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u8p, C.c_int32]
+    L.eg_policy_apply_episode.restype = C.c_int32
+    L.eg_policy_apply_episode.argtypes = [C.c_void_p, _dp, _i32p, _u8p, _i32p, _u8p, C.c_uint64]
+    L.eg_score_metrics.restype = C.c_double
+    L.eg_score_metrics.argtypes = [_dp, C.c_int32]
+    _lib = L
+    return L
+
+
+class EirgridError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != EG_OK:
+        msg = lib().eg_last_error()
+        raise EirgridError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

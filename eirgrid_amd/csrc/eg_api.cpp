@@ -1,0 +1,358 @@
+// eg_api.cpp — C ABI glue: context, HBM residency of tables / snapshot / outputs, launches, timing.
+// There is no CPU execution path behind these entry points: without a HIP device eg_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "eg_internal.h"
+
+namespace eg {
+namespace {
+thread_local std::string g_error;
+}
+void set_error(const std::string& s) { g_error = s; }
+}  // namespace eg
+
+using namespace eg;
+
+#define EG_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      set_error(std::string(#call) + ": " + hipGetErrorString(e_));                           \
+      return EG_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+struct eg_host_tables {
+  HostTables H;
+  std::map<std::string, std::pair<const double*, int64_t>> f64;
+  std::map<std::string, std::pair<const int32_t*, int64_t>> i32;
+  void index() {
+    auto F = [&](const char* n, const std::vector<double>& v) { f64[n] = {v.data(), (int64_t)v.size()}; };
+    auto I = [&](const char* n, const std::vector<int32_t>& v) { i32[n] = {v.data(), (int64_t)v.size()}; };
+    F("usage", H.usage); F("population", H.population); F("pre_co2", H.pre_co2); F("pre_tg", H.pre_tg); F("pre_ig", H.pre_ig);
+    F("pre_sg", H.pre_sg); F("pre_optot", H.pre_optot); F("te", H.te); F("coastf", H.coastf); F("dr", H.dr); F("m03", H.m03);
+    F("t12", H.t12); F("cc", H.cc); F("out_mw", H.out_mw); F("co2_t", H.co2_t); F("offv", H.offv); F("offc", H.offc);
+    F("inflation", H.inflation); F("carbon_price", H.carbon_price);
+    f64["size_factor"] = {&H.size_factor, 1};
+    I("pre_opcnt", H.pre_opcnt); I("cls", H.cls); I("rclass", H.rclass); I("marine", H.marine); I("reach", H.reach);
+    I("existing_online", H.existing_online);
+  }
+};
+
+struct eg_ctx {
+  int device = 0;
+  eg_host_tables tables;
+  std::vector<void*> allocs;        // table allocations
+  DevTables dev{};
+  // snapshot in HBM
+  double *d_w = nullptr, *d_dw = nullptr, *d_cw = nullptr;
+  int32_t *d_best_off = nullptr, *d_bestd_off = nullptr;
+  uint8_t *d_best = nullptr, *d_bestd = nullptr;
+  size_t best_cap = 0, bestd_cap = 0;
+  DevSnapshot snap{};
+  bool snap_valid = false;
+  // outputs
+  DevOut out{};
+  uint32_t out_cap = 0, last_n = 0;
+  uint8_t* d_mask = nullptr; uint32_t mask_cap = 0;
+  // timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double total_ms = 0.0; int32_t n_launches = 0;
+  bool timing_pending = false;
+};
+
+namespace {
+
+template <typename T>
+int upload_vec(eg_ctx* c, const std::vector<T>& v, const T** dst) {
+  void* p = nullptr;
+  size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
+  EG_HIP(hipMalloc(&p, bytes));
+  c->allocs.push_back(p);
+  if (!v.empty()) EG_HIP(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  *dst = static_cast<const T*>(p);
+  return EG_OK;
+}
+
+void free_outputs(eg_ctx* c) {
+  void* ptrs[] = {c->out.metrics, c->out.yearly, c->out.status, c->out.n_run, c->out.n_def, c->out.n_act, c->out.run_log,
+                  c->out.def_log, c->out.act_log, c->out.n_gens, c->out.gen_cell, c->out.gen_pack, c->out.n_offsets,
+                  c->out.off_pack, c->out.n_draws, c->out.bytes_moved};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  c->out = DevOut{}; c->out_cap = 0;
+}
+
+int ensure_outputs(eg_ctx* c, uint32_t n) {
+  if (n <= c->out_cap) return EG_OK;
+  free_outputs(c);
+  const size_t N = n;
+  EG_HIP(hipMalloc((void**)&c->out.metrics, N * 4 * sizeof(double)));
+  EG_HIP(hipMalloc((void**)&c->out.yearly, N * EG_YEARS * EG_YEARLY_FIELDS * sizeof(double)));
+  EG_HIP(hipMalloc((void**)&c->out.status, N * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.n_run, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.n_def, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.n_act, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.run_log, N * EG_RUN_CAP));
+  EG_HIP(hipMalloc((void**)&c->out.def_log, N * EG_DEF_CAP));
+  EG_HIP(hipMalloc((void**)&c->out.act_log, N * EG_ACT_CAP));
+  EG_HIP(hipMalloc((void**)&c->out.n_gens, N * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.gen_cell, N * EG_MAX_GENS * sizeof(uint16_t)));
+  EG_HIP(hipMalloc((void**)&c->out.gen_pack, N * EG_MAX_GENS * sizeof(uint16_t)));
+  EG_HIP(hipMalloc((void**)&c->out.n_offsets, N * sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&c->out.off_pack, N * EG_MAX_OFFSETS * sizeof(uint16_t)));
+  EG_HIP(hipMalloc((void**)&c->out.n_draws, N * sizeof(unsigned long long)));
+  EG_HIP(hipMalloc((void**)&c->out.bytes_moved, N * sizeof(double)));
+  // zero the year-count tables once so episodes that end early leave defined data behind
+  EG_HIP(hipMemset(c->out.n_run, 0, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMemset(c->out.n_def, 0, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMemset(c->out.n_act, 0, N * EG_YEARS * sizeof(int32_t)));
+  EG_HIP(hipMemset(c->out.yearly, 0, N * EG_YEARS * EG_YEARLY_FIELDS * sizeof(double)));
+  c->out_cap = n;
+  return EG_OK;
+}
+
+int collect_timing(eg_ctx* c) {
+  if (!c->timing_pending) return EG_OK;
+  EG_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  EG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->total_ms += double(ms); c->n_launches += 1; c->timing_pending = false;
+  return EG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eg_last_error(void) { return g_error.c_str(); }
+
+int32_t eg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
+  if (!world || world->n_settlements < 0 || world->n_existing < 0 || world->n_coast < 0) { set_error("eg_create: bad world"); return nullptr; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("eg_create: no HIP device (this library has no CPU path)"); return nullptr; }
+  if (device_ordinal < 0 || device_ordinal >= n) { set_error("eg_create: device ordinal out of range"); return nullptr; }
+  if (hipSetDevice(device_ordinal) != hipSuccess) { set_error("eg_create: hipSetDevice failed"); return nullptr; }
+  eg_ctx* c = new eg_ctx();
+  c->device = device_ordinal;
+  build_tables(*world, c->tables.H);
+  c->tables.index();
+  const HostTables& H = c->tables.H;
+  DevTables& D = c->dev;
+  int rc = EG_OK;
+  auto up = [&](auto& vec, auto** dst) { if (rc == EG_OK) rc = upload_vec(c, vec, dst); };
+  up(H.usage, &D.usage); up(H.population, &D.population);
+  up(H.pre_co2, &D.pre_co2); up(H.pre_tg, &D.pre_tg); up(H.pre_ig, &D.pre_ig); up(H.pre_sg, &D.pre_sg);
+  up(H.pre_optot, &D.pre_optot); up(H.pre_opcnt, &D.pre_opcnt);
+  up(H.te, &D.te); up(H.coastf, &D.coastf); up(H.dr, &D.dr);
+  up(H.m03, &D.m03); up(H.t12, &D.t12); up(H.cc, &D.cc); up(H.out_mw, &D.out_mw); up(H.co2_t, &D.co2_t);
+  up(H.cls, &D.cls); up(H.rclass, &D.rclass); up(H.marine, &D.marine); up(H.reach, &D.reach);
+  up(H.offv, &D.offv); up(H.offc, &D.offc); up(H.inflation, &D.inflation); up(H.carbon_price, &D.carbon_price);
+  D.size_factor = H.size_factor; D.n_existing = world->n_existing;
+  if (rc == EG_OK && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
+  if (rc == EG_OK) {
+    size_t wb = sizeof(double) * EG_YEARS * EG_N_ACTIONS, db = sizeof(double) * EG_YEARS * EG_N_DEFICIT, cb = sizeof(double) * EG_YEARS * EG_N_COUNTS;
+    if (hipMalloc((void**)&c->d_w, wb) != hipSuccess || hipMalloc((void**)&c->d_dw, db) != hipSuccess ||
+        hipMalloc((void**)&c->d_cw, cb) != hipSuccess || hipMalloc((void**)&c->d_best_off, 27 * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_bestd_off, 27 * sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP; }
+  }
+  if (rc != EG_OK) { eg_destroy(c); return nullptr; }
+  return c;
+}
+
+void eg_destroy(eg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : c->allocs) (void)hipFree(p);
+  void* snap[] = {c->d_w, c->d_dw, c->d_cw, c->d_best_off, c->d_bestd_off, c->d_best, c->d_bestd, c->d_mask};
+  for (void* p : snap) if (p) (void)hipFree(p);
+  free_outputs(c);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+}
+
+eg_host_tables* eg_host_tables_create(const eg_world* world) {
+  if (!world || world->n_settlements < 0 || world->n_existing < 0 || world->n_coast < 0) { set_error("eg_host_tables_create: bad world"); return nullptr; }
+  eg_host_tables* h = new eg_host_tables();
+  build_tables(*world, h->H);
+  h->index();
+  return h;
+}
+void eg_host_tables_free(eg_host_tables* h) { delete h; }
+int32_t eg_host_tables_f64(const eg_host_tables* h, const char* name, const double** ptr, int64_t* len) {
+  if (!h || !name || !ptr || !len) return EG_ERR_BAD_ARG;
+  auto it = h->f64.find(name);
+  if (it == h->f64.end()) { set_error(std::string("eg_host_tables_f64: unknown table ") + name); return EG_ERR_BAD_ARG; }
+  *ptr = it->second.first; *len = it->second.second;
+  return EG_OK;
+}
+int32_t eg_host_tables_i32(const eg_host_tables* h, const char* name, const int32_t** ptr, int64_t* len) {
+  if (!h || !name || !ptr || !len) return EG_ERR_BAD_ARG;
+  auto it = h->i32.find(name);
+  if (it == h->i32.end()) { set_error(std::string("eg_host_tables_i32: unknown table ") + name); return EG_ERR_BAD_ARG; }
+  *ptr = it->second.first; *len = it->second.second;
+  return EG_OK;
+}
+
+int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o) {
+  if (!c || !s || !s->weights || !s->deficit_weights) { set_error("eg_upload_snapshot: bad argument"); return EG_ERR_BAD_ARG; }
+  if (o && o->enable_construction_delays) { set_error("enable_construction_delays is not implemented on the device (SURVEY §8(f) N4)"); return EG_ERR_UNSUPPORTED; }
+  if (s->iterations_without_improvement > 500u) { set_error("iterations_without_improvement > 500 (power-scaled sampling, sampling.rs:190-220) is not implemented on the device yet"); return EG_ERR_UNSUPPORTED; }
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipMemcpy(c->d_w, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS, hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(c->d_dw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT, hipMemcpyHostToDevice));
+  if (s->count_weights) EG_HIP(hipMemcpy(c->d_cw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS, hipMemcpyHostToDevice));
+  DevSnapshot& S = c->snap;
+  S = DevSnapshot{};
+  S.w = c->d_w; S.dw = c->d_dw; S.cw = s->count_weights ? c->d_cw : nullptr;
+  S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
+  S.has_best = s->has_best ? 1 : 0;
+  // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)
+  const double final_impact = s->has_best ? eg_score_metrics(s->best_metrics, 0) : 0.0;
+  double rel = final_impact;
+  if (s->has_best) { const double best_score = eg_score_metrics(s->best_metrics, 0); rel = best_score > 0.0 ? (final_impact - best_score) / best_score : final_impact; }
+  S.rel_improvement = rel; S.immediate_weight = rel > 0.0 ? 0.7 : 0.3;
+  S.noop_boost = (s->has_best && s->best_metrics[0] <= 0.0 && s->best_metrics[2] > 50000000000.0 * 8.0) ? 1 : 0;   // learning.rs:82
+  const double scaled = std::pow(s->exploration_rate, 0.5);   // sampling.rs:425-427
+  S.heur_min = uint32_t(std::round(2.0 / scaled)); S.heur_max = uint32_t(std::round(12.0 / scaled));
+  const bool have_lists = s->has_best && s->best_count && s->best_actions && s->best_deficit_count && s->best_deficit_actions;
+  S.has_best_actions = have_lists ? 1 : 0; S.has_best_deficit = have_lists ? 1 : 0;
+  int32_t off[27] = {0}, offd[27] = {0};
+  if (have_lists) for (int y = 0; y < EG_YEARS; ++y) { off[y + 1] = off[y] + s->best_count[y]; offd[y + 1] = offd[y] + s->best_deficit_count[y]; }
+  EG_HIP(hipMemcpy(c->d_best_off, off, sizeof(off), hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(c->d_bestd_off, offd, sizeof(offd), hipMemcpyHostToDevice));
+  auto put = [&](uint8_t** d, size_t* cap, const uint8_t* src, size_t n) -> int {
+    if (n + 1 > *cap) { if (*d) (void)hipFree(*d); *d = nullptr; EG_HIP(hipMalloc((void**)d, n + 64)); *cap = n + 64; }
+    if (n) EG_HIP(hipMemcpy(*d, src, n, hipMemcpyHostToDevice));
+    return EG_OK;
+  };
+  int rc = put(&c->d_best, &c->best_cap, have_lists ? s->best_actions : nullptr, have_lists ? size_t(off[26]) : 0);
+  if (rc != EG_OK) return rc;
+  rc = put(&c->d_bestd, &c->bestd_cap, have_lists ? s->best_deficit_actions : nullptr, have_lists ? size_t(offd[26]) : 0);
+  if (rc != EG_OK) return rc;
+  S.best_off = c->d_best_off; S.best_actions = c->d_best; S.bestd_off = c->d_bestd_off; S.bestd_actions = c->d_bestd;
+  S.enable_energy_sales = o ? (o->enable_energy_sales ? 1 : 0) : 1;
+  S.write_yearly = o ? (o->write_yearly ? 1 : 0) : 1;
+  c->snap_valid = true;
+  return EG_OK;
+}
+
+int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, const uint8_t* replay_mask) {
+  if (!c || !c->snap_valid) { set_error("eg_rollout_launch: upload a snapshot first"); return EG_ERR_BAD_ARG; }
+  if (n == 0) { c->last_n = 0; return EG_OK; }
+  EG_HIP(hipSetDevice(c->device));
+  int rc = ensure_outputs(c, n);
+  if (rc != EG_OK) return rc;
+  const uint8_t* d_mask = nullptr;
+  if (replay_mask) {
+    if (n > c->mask_cap) { if (c->d_mask) (void)hipFree(c->d_mask); c->d_mask = nullptr; EG_HIP(hipMalloc((void**)&c->d_mask, n)); c->mask_cap = n; }
+    EG_HIP(hipMemcpy(c->d_mask, replay_mask, n, hipMemcpyHostToDevice));
+    d_mask = c->d_mask;
+  }
+  rc = collect_timing(c);
+  if (rc != EG_OK) return rc;
+  EG_HIP(hipEventRecord(c->ev0, nullptr));
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, nullptr);
+  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  EG_HIP(hipEventRecord(c->ev1, nullptr));
+  c->timing_pending = true;
+  c->last_n = n;
+  return EG_OK;
+}
+
+int32_t eg_sync(eg_ctx* c) {
+  if (!c) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipDeviceSynchronize());
+  return collect_timing(c);
+}
+
+int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
+  if (!c || !o) return EG_ERR_BAD_ARG;
+  int rc = eg_sync(c);
+  if (rc != EG_OK) return rc;
+  const size_t N = c->last_n;
+  if (N == 0) return EG_OK;
+#define EG_GET(field, count, type) \
+  if (o->field) EG_HIP(hipMemcpy(o->field, c->out.field, N * (count) * sizeof(type), hipMemcpyDeviceToHost))
+  EG_GET(metrics, 4, double); EG_GET(yearly, EG_YEARS * EG_YEARLY_FIELDS, double); EG_GET(status, 1, int32_t);
+  EG_GET(n_run, EG_YEARS, int32_t); EG_GET(n_def, EG_YEARS, int32_t); EG_GET(n_act, EG_YEARS, int32_t);
+  EG_GET(run_log, EG_RUN_CAP, uint8_t); EG_GET(def_log, EG_DEF_CAP, uint8_t); EG_GET(act_log, EG_ACT_CAP, uint8_t);
+  EG_GET(n_gens, 1, int32_t); EG_GET(gen_cell, EG_MAX_GENS, uint16_t); EG_GET(gen_pack, EG_MAX_GENS, uint16_t);
+  EG_GET(n_offsets, 1, int32_t); EG_GET(off_pack, EG_MAX_OFFSETS, uint16_t);
+  EG_GET(bytes_moved, 1, double);
+#undef EG_GET
+  if (o->n_draws) EG_HIP(hipMemcpy(o->n_draws, c->out.n_draws, N * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return EG_OK;
+}
+
+int32_t eg_rollout_batch(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o, uint64_t seed, uint64_t first_index,
+                         uint32_t n, const uint8_t* replay_mask, eg_episode_out* out) {
+  int rc = eg_upload_snapshot(c, s, o);
+  if (rc != EG_OK) return rc;
+  rc = eg_rollout_launch(c, seed, first_index, n, replay_mask);
+  if (rc != EG_OK) return rc;
+  return eg_fetch(c, out);
+}
+
+int32_t eg_timing_reset(eg_ctx* c) {
+  if (!c) return EG_ERR_BAD_ARG;
+  int rc = collect_timing(c);
+  c->total_ms = 0.0; c->n_launches = 0;
+  return rc;
+}
+int32_t eg_timing_read(eg_ctx* c, double* total_ms, int32_t* n_launches) {
+  if (!c) return EG_ERR_BAD_ARG;
+  int rc = collect_timing(c);
+  if (total_ms) *total_ms = c->total_ms;
+  if (n_launches) *n_launches = c->n_launches;
+  return rc;
+}
+
+int32_t eg_update_stats(eg_ctx* c, double* d_stats) {
+  if (!c || !d_stats) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipMemsetAsync(d_stats, 0, sizeof(double) * EG_STATS_LEN, nullptr));
+  int lr = launch_update_stats(c->snap, c->out, c->last_n, d_stats, nullptr);
+  if (lr != 0) { set_error(std::string("k_update_stats launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  return EG_OK;
+}
+
+int32_t eg_place(eg_ctx* c, int32_t gen_type, int32_t year_index, const uint16_t* extra_cells, int32_t n_extra,
+                 int32_t* out_cell, double* out_score) {
+  if (!c || gen_type < 0 || gen_type >= EG_N_TYPES || year_index < 0 || year_index >= EG_YEARS || n_extra < 0 || n_extra > EG_MAX_GENS) {
+    set_error("eg_place: bad argument"); return EG_ERR_BAD_ARG;
+  }
+  for (int i = 0; i < n_extra; ++i) if (extra_cells[i] >= EG_CELLS) { set_error("eg_place: cell out of range"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  uint16_t* d_cells = nullptr; int32_t* d_cell = nullptr; double* d_score = nullptr;
+  EG_HIP(hipMalloc((void**)&d_cells, sizeof(uint16_t) * (n_extra > 0 ? n_extra : 1)));
+  EG_HIP(hipMalloc((void**)&d_cell, sizeof(int32_t)));
+  EG_HIP(hipMalloc((void**)&d_score, sizeof(double)));
+  if (n_extra) EG_HIP(hipMemcpy(d_cells, extra_cells, sizeof(uint16_t) * n_extra, hipMemcpyHostToDevice));
+  int lr = launch_place(c->dev, gen_type, year_index, d_cells, n_extra, d_cell, d_score, nullptr);
+  if (lr != 0) { set_error(std::string("k_place launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  int32_t cell = -1; double score = 0.0;
+  EG_HIP(hipMemcpy(&cell, d_cell, sizeof(cell), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(&score, d_score, sizeof(score), hipMemcpyDeviceToHost));
+  (void)hipFree(d_cells); (void)hipFree(d_cell); (void)hipFree(d_score);
+  if (out_cell) *out_cell = cell;
+  if (out_score) *out_score = score;
+  return EG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,626 @@
+// eg_rollout.hip — CDNA4 (gfx950) kernels of the rollout engine.
+//
+// One wavefront (64 lanes, one workgroup) runs one 2025–2050 episode from start to finish; a batch is a grid of
+// episodes.  Control flow of an episode is wave-uniform (every lane carries the same scalar state), the lanes
+// fan out over (a) the 51x51 candidate grid of the placement search, which lives in LDS, (b) the penalty box of
+// each generator, (c) the per-year table rows and the weight-table updates.  All sums and products are folded
+// in the reference's list order and every transcendental is a host-built table (eg_tables.cpp), so device code
+// is + - * / compare only and reproduces the CPU oracle bit for bit.  Build: -ffp-contract=off (no FMA).
+//
+// Reference (paths relative to /root/reference/aiSimulator/src/):
+//   episode        core/simulation.rs:22-317, core/iteration.rs:57-74
+//   deficit loop   core/simulation.rs:319-522
+//   sampling       ai/learning/weights/sampling.rs:76-443
+//   nudges         ai/learning/weights/learning.rs:21-88, deficit.rs:82-135
+//   apply_action   core/actions.rs:40-204
+//   placement      gpu/metal_location_search.rs:110-176
+//   metrics        analysis/metrics_calculation.rs:7-175, ai/metrics/scoring.rs:46-85
+//   RNG            rand 0.8.5 StdRng = ChaCha12 behind rand_core BlockRng (Cargo.lock:763-785)
+#include <hip/hip_runtime.h>
+
+#include "eg_internal.h"
+
+namespace eg {
+namespace {
+
+constexpr int kWave = 64;
+constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
+constexpr double kMaxWeight = 0.999;    // constants.rs:15
+constexpr double kMaxCost = 50000000000.0;   // config/constants.rs:115
+constexpr int kBattery = 12, kPeaker = 8;
+constexpr int kNothing = 60, kFirstOffset = 45, kFirstOther = 57;
+
+// deficit-table slot -> generator type (core.rs:130-149) and the inverse
+__constant__ int c_deficit_type[14] = {8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14};
+__constant__ int c_deficit_slot[15] = {5, 6, 10, 11, 7, 9, -1, 1, 0, 4, 8, 3, 2, 12, 13};
+
+struct __align__(16) Smem {
+  double fld[kCells];                 // placement score field of the current search
+  double w[64];                       // this year's main weights (61 used)
+  double dw[16];                      // this year's deficit weights (15 used)
+  uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
+  uint16_t gcell[EG_MAX_GENS];        // cell | type << 12
+  uint16_t opack[EG_MAX_OFFSETS];     // type | year << 4 | mult << 9
+  uint8_t gbm[EG_MAX_GENS];           // build-year index | mult << 5
+  uint8_t ydef[256];                  // this year's deficit actions (success bonus, simulation.rs:505-519)
+};
+static_assert(sizeof(Smem) <= 27306, "six episodes per CU need <= 160 KiB / 6 of LDS each");
+
+struct Rng {
+  uint32_t key[8];
+  unsigned long long counter;
+  int index;
+  unsigned long long words;
+};
+
+struct Agg {   // aggregates of the map at the current point of the year (map_handler.rs:819-965)
+  double co2, tg, ig, sg, optot, gcost, ocost, gcost_prev, ocost_prev, offs, usage;
+  int opcnt;
+};
+struct State { double net, opinion, balance, cost; };   // ActionResult, simulation_metrics.rs:13-18
+
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dabs(double a) { return a < 0.0 ? -a : a; }
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
+
+#define EG_QR(a, b, c, d)                                                         \
+  a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12);           \
+  a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
+
+__device__ void chacha12_block(const uint32_t* key, unsigned long long counter, uint32_t* out) {
+  uint32_t s[16], x[16];
+  s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[4 + i] = key[i];
+  s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0u; s[15] = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
+    EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+}
+
+__device__ void rng_seed(Rng& r, unsigned long long state) {   // rand_core 0.6.4 seed_from_u64
+  const unsigned long long MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    state = state * MUL + INC;
+    uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+    uint32_t rot = (uint32_t)(state >> 59);
+    r.key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+  }
+  r.counter = 0; r.index = 64; r.words = 0;
+}
+__device__ void rng_refill(Rng& r, Smem& sm, int lane) {   // four consecutive blocks, one per lane 0..3
+  __syncthreads();
+  if (lane < 4) chacha12_block(r.key, r.counter + (unsigned long long)lane, &sm.rng[16 * lane]);
+  r.counter += 4;
+  __syncthreads();
+}
+__device__ unsigned long long rng_u64(Rng& r, Smem& sm, int lane) {   // BlockRng::next_u64
+  r.words += 1;
+  if (r.index < 63) {
+    unsigned long long v = ((unsigned long long)sm.rng[r.index + 1] << 32) | sm.rng[r.index];
+    r.index += 2;
+    return v;
+  }
+  if (r.index >= 64) {
+    rng_refill(r, sm, lane); r.index = 2;
+    return ((unsigned long long)sm.rng[1] << 32) | sm.rng[0];
+  }
+  unsigned long long x = sm.rng[63];
+  rng_refill(r, sm, lane); r.index = 1;
+  return ((unsigned long long)sm.rng[0] << 32) | x;
+}
+__device__ uint32_t rng_u32(Rng& r, Smem& sm, int lane) {   // BlockRng::next_u32
+  r.words += 1;
+  if (r.index >= 64) { rng_refill(r, sm, lane); r.index = 0; }
+  uint32_t v = sm.rng[r.index];
+  r.index += 1;
+  return v;
+}
+__device__ double rng_f64(Rng& r, Smem& sm, int lane) {   // Standard: 53 bits, [0,1)
+  return (double)(rng_u64(r, sm, lane) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ unsigned long long rng_range64(Rng& r, Smem& sm, int lane, unsigned long long range) {
+  unsigned long long zone = (range << __clzll((long long)range)) - 1ull;   // uniform.rs sample_single_inclusive
+  for (int guard = 0; guard < 4096; ++guard) {
+    unsigned long long v = rng_u64(r, sm, lane);
+    unsigned long long hi = __umul64hi(v, range), lo = v * range;
+    if (lo <= zone) return hi;
+  }
+  return 0;
+}
+__device__ uint32_t rng_range32(Rng& r, Smem& sm, int lane, uint32_t range) {
+  uint32_t zone = (range << __clz((int)range)) - 1u;
+  for (int guard = 0; guard < 4096; ++guard) {
+    uint32_t v = rng_u32(r, sm, lane);
+    unsigned long long m = (unsigned long long)v * range;
+    if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+  }
+  return 0;
+}
+
+__device__ __forceinline__ State state_of(const Agg& a) {   // simulation.rs:122-135
+  State s;
+  s.net = a.co2 - a.offs;
+  s.opinion = a.opcnt > 0 ? a.optot / (double)a.opcnt : 1.0;
+  s.balance = ((a.tg + a.ig) + a.sg) - a.usage;
+  s.cost = a.gcost + a.ocost;
+  return s;
+}
+__device__ double evaluate_impact(const State& cur, const State& nxt) {   // scoring.rs:46-85 (mode None)
+  if (cur.net > 0.0) return (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0);
+  double cost_change = nxt.cost - cur.cost;
+  double cost_improvement = -cost_change / dmax(dabs(cur.cost), 1.0);
+  double opinion_improvement = (nxt.opinion - cur.opinion) / dmax(dabs(cur.opinion), 1.0);
+  double cost_weight = cur.cost > kMaxCost * 8.0 ? 0.8 : 0.5;
+  double opinion_weight = 1.0 - cost_weight;
+  return cost_improvement * cost_weight + opinion_improvement * opinion_weight;
+}
+
+// ---- placement: arg-max over the 51x51 distinct candidates (Q10) -------------------------------------------
+// fld[c] starts from te[year][class][c] (settlement product, then existing plant, in list order), is multiplied by
+// d/R for every generator added so far in list order, then by the coast factor (marine types) and the size
+// factor.  Strict '>' against a running best that starts at 0.0, candidates in (i, j) order: first maximum wins.
+__device__ int place_search(const DevTables& T, Smem& sm, int lane, int yi, int type, int ngen, double* best_score) {
+  const int rc = T.rclass[type];
+  const double* te = T.te + ((size_t)yi * kRadiusClasses + rc) * kCells;
+  for (int c = lane; c < kCells; c += kWave) sm.fld[c] = te[c];
+  __syncthreads();
+  const int reach = T.reach[rc];
+  const int side = 2 * reach + 1, box = side * side;
+  const double* dr = T.dr + (size_t)rc * 169;
+  for (int g = 0; g < ngen; ++g) {
+    const int gc = sm.gcell[g] & 0xFFF;
+    const int gi = gc / kGrid, gj = gc - gi * kGrid;
+    for (int idx = lane; idx < box; idx += kWave) {
+      const int bi = idx / side, bj = idx - bi * side;
+      const int di = bi - reach, dj = bj - reach;
+      const int ci = gi + di, cj = gj + dj;
+      if (ci >= 0 && ci < kGrid && cj >= 0 && cj < kGrid) {
+        const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+        const int c = ci * kGrid + cj;
+        sm.fld[c] = sm.fld[c] * dr[adi * 13 + adj];
+      }
+    }
+    __syncthreads();
+  }
+  const bool marine = T.marine[type] != 0;
+  double best = 0.0; int best_c = kCells;
+  for (int c = lane; c < kCells; c += kWave) {
+    double s = sm.fld[c];
+    if (marine) s = s * T.coastf[c];
+    s = s * T.size_factor;
+    if (s > best) { best = s; best_c = c; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    double ob = __shfl_xor(best, off);
+    int oc = __shfl_xor(best_c, off);
+    if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+  }
+  __syncthreads();
+  if (best_score) *best_score = best;
+  return best > 0.0 ? best_c : -1;
+}
+
+// ---- weight nudges -----------------------------------------------------------------------------------------
+__device__ void update_weights(const DevSnapshot& S, Smem& sm, int lane, int action, double improvement) {
+  // learning.rs:21-88; rel_improvement / immediate_weight are the host-evaluated :37-54
+  const double combined = S.immediate_weight * improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
+  const double adj = combined > 0.0 ? 1.0 + (S.learning_rate * combined)
+                                    : 1.0 / (1.0 + (S.learning_rate * dabs(combined)));
+  __syncthreads();
+  if (lane == 0) sm.w[action] = dmin(dmax(sm.w[action] * adj, kMinWeight), kMaxWeight);
+  __syncthreads();
+  if (combined < 0.0) {
+    const double boost = 1.0 + (S.learning_rate * 0.1);
+    if (lane < kFirstOffset && lane != action) sm.w[lane] = dmin(sm.w[lane] * boost, kMaxWeight);
+    __syncthreads();
+    if (S.noop_boost && lane == 0) sm.w[kNothing] = dmin(sm.w[kNothing] * (1.0 + S.learning_rate * 0.2), kMaxWeight);
+    __syncthreads();
+  }
+}
+__device__ void update_deficit_weights(const DevSnapshot& S, Smem& sm, int lane, int action, double improvement) {
+  // deficit.rs:82-135; every action that reaches here is AddGenerator(type, 100 %)
+  int slot = -1;
+  if (action < kFirstOffset && (action % 3) == 0) slot = c_deficit_slot[action / 3];
+  else if (action == kNothing) slot = 14;
+  if (slot < 0) return;
+  const double adj = improvement > 0.0 ? 1.0 + (S.learning_rate * improvement * 1.5)
+                                       : 1.0 / (1.0 + (S.learning_rate * dabs(improvement) * 1.5));
+  __syncthreads();
+  if (lane == 0) sm.dw[slot] = dmin(dmax(sm.dw[slot] * adj, kMinWeight), kMaxWeight);
+  __syncthreads();
+  if (improvement < 0.0) {
+    const double boost = 1.0 + (S.learning_rate * 0.1);
+    if (lane < 14 && lane != slot) sm.dw[lane] = dmin(sm.dw[lane] * boost, kMaxWeight);
+    __syncthreads();
+  }
+}
+
+// ---- sampling (canonical table order; see include/eirgrid_hip.h) -------------------------------------------
+__device__ int smart_fallback(Rng& r, Smem& sm, int lane, int year) {   // sampling.rs:445-490
+  const uint32_t offw = year < 2035 ? 5u : (year < 2045 ? 15u : 25u);
+  const int acts[7] = {0, 3, 12, 3 * kBattery, kFirstOffset, kFirstOffset + 6, 21};
+  const uint32_t wts[7] = {15u, 10u, 15u, year < 2035 ? 10u : 20u, offw, offw, year < 2035 ? 15u : (year < 2045 ? 10u : 5u)};
+  uint32_t total = 0;
+  for (int i = 0; i < 7; ++i) total += wts[i];
+  uint32_t choice = rng_range32(r, sm, lane, total);
+  for (int i = 0; i < 7; ++i) { if (choice < wts[i]) return acts[i]; choice -= wts[i]; }
+  return 3 * kBattery;
+}
+__device__ int smart_deficit_fallback(Rng& r, Smem& sm, int lane) {   // sampling.rs:492-528
+  const int acts[6] = {3 * kPeaker, 3 * kBattery, 21, 0, 3, 12};
+  const uint32_t wts[6] = {30u, 30u, 20u, 10u, 0u, 3u};
+  uint32_t choice = rng_range32(r, sm, lane, 93u);
+  for (int i = 0; i < 6; ++i) { if (choice < wts[i]) return acts[i]; choice -= wts[i]; }
+  return 3 * kBattery;
+}
+__device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Smem& sm, int lane) {   // sampling.rs:147-237
+  const double eps = S.stall > 100u ? S.exploration_rate * (1.0 / (1.0 + 0.01 * (double)S.stall)) : S.exploration_rate;
+  const bool explore = rng_f64(r, sm, lane) < eps;
+  if (explore) return (int)rng_range64(r, sm, lane, (unsigned long long)EG_N_ACTIONS);
+  double total = 0.0;
+  for (int a = 0; a < EG_N_ACTIONS; ++a) total += sm.w[a];
+  if (total <= 0.0) return 3 * kPeaker;
+  double v = rng_f64(r, sm, lane) * total;
+  for (int a = 0; a < EG_N_ACTIONS; ++a) { v -= sm.w[a]; if (v <= 0.0) return a; }
+  return 3 * kPeaker;
+}
+__device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Smem& sm, int lane) {   // sampling.rs:315-377
+  const bool explore = rng_f64(r, sm, lane) < S.exploration_rate;
+  if (explore) return 3 * c_deficit_type[(int)rng_range64(r, sm, lane, 14ull)];
+  double total = 0.0;
+  for (int i = 0; i < 14; ++i) total += sm.dw[i];
+  if (total <= 0.0) return 3 * kPeaker;
+  double v = rng_f64(r, sm, lane) * total;
+  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; if (v <= 0.0) return 3 * c_deficit_type[i]; }
+  return 3 * kPeaker;
+}
+
+struct Episode {   // wave-uniform bookkeeping of one episode
+  int ngen, noff;
+  int run_pos, def_pos, act_pos;      // flat log cursors
+  int n_run_y, n_def_y, n_act_y;      // this year's counts
+  int status;
+  double bytes;
+};
+
+__global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
+                                                   unsigned long long first_index, uint32_t n_episodes,
+                                                   const uint8_t* __restrict__ replay_mask) {
+  __shared__ Smem sm;
+  const int lane = threadIdx.x;
+  const uint32_t e = blockIdx.x;
+  if (e >= n_episodes) return;
+  const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
+  const int n_existing = T.n_existing;
+
+  Rng rng;
+  rng_seed(rng, seed + first_index + (unsigned long long)e);   // simulation.rs:50-53, one stream per episode
+
+  Episode ep;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32.0;
+  uint8_t* run_log = O.run_log + (size_t)e * EG_RUN_CAP;
+  uint8_t* def_log = O.def_log + (size_t)e * EG_DEF_CAP;
+  uint8_t* act_log = O.act_log + (size_t)e * EG_ACT_CAP;
+  uint16_t* gen_cell = O.gen_cell + (size_t)e * EG_MAX_GENS;
+  uint16_t* gen_pack = O.gen_pack + (size_t)e * EG_MAX_GENS;
+  uint16_t* off_pack = O.off_pack + (size_t)e * EG_MAX_OFFSETS;
+
+  double gcost_end = 0.0, ocost_end = 0.0;                 // last year's end-of-year capital sums
+  double total_cost = 0.0, total_credit = 0.0, total_sales = 0.0;   // accumulators of metrics_calculation.rs:133-153
+  double last_net = 0.0, last_opinion = 0.0, last_capital = 0.0, last_balance = 0.0;
+
+  for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
+    const int year = 2025 + yi;
+    // this year's policy rows -> LDS
+    __syncthreads();
+    if (lane < EG_N_ACTIONS) sm.w[lane] = S.w[yi * EG_N_ACTIONS + lane];
+    if (lane < EG_N_DEFICIT) sm.dw[lane] = S.dw[yi * EG_N_DEFICIT + lane];
+    __syncthreads();
+    ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
+
+    // ---- aggregates at the start of the year: existing plant first, then every generator in list order ----
+    Agg a;
+    a.co2 = T.pre_co2[yi]; a.tg = T.pre_tg[yi]; a.ig = T.pre_ig[yi]; a.sg = T.pre_sg[yi];
+    a.optot = T.pre_optot[yi]; a.opcnt = T.pre_opcnt[yi]; a.usage = T.usage[yi];
+    a.gcost = 0.0; a.ocost = 0.0; a.offs = 0.0;
+    a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
+    {
+      const double* ccy = T.cc + (size_t)yi * kTypes * kYears * kMults * 2;
+      const double* t12y = T.t12 + (size_t)yi * kTypes;
+      for (int g = 0; g < ep.ngen; ++g) {
+        const int gc = sm.gcell[g], bm = sm.gbm[g];
+        const int cell = gc & 0xFFF, t = gc >> 12, b = bm & 31, m = bm >> 5;
+        const double* cc = ccy + ((size_t)(t * kYears + b) * kMults + m) * 2;
+        a.gcost += cc[0];
+        a.co2 += T.co2_t[t];
+        const double out = T.out_mw[t];
+        const int cls = T.cls[t];
+        if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
+        a.optot += (T.m03[cell] + t12y[t]) + cc[1];
+        a.opcnt += 1;
+      }
+      const double* offvy = T.offv + (size_t)yi * kOffsetTypes * kYears;
+      const double* offcy = T.offc + (size_t)yi * kOffsetTypes * kMults;
+      for (int k = 0; k < ep.noff; ++k) {
+        const int p = sm.opack[k];
+        const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+        a.offs += offvy[ot * kYears + b];
+        a.ocost += offcy[ot * kMults + m];
+      }
+    }
+    ep.bytes += 2.0 * (double)(n_existing + ep.ngen) * 56.0 + 2.0 * (double)ep.noff * 8.0 + 184.0;
+
+    // apply one action to the map (actions.rs:40-204) and fold it into the aggregates
+    auto apply = [&](int action) {
+      if (action < kFirstOffset) {
+        const int t = action / 3, m = action - 3 * t;
+        ep.bytes += (double)kCells * 8.0 + (double)(n_existing + ep.ngen) * 16.0;
+        const int cell = place_search(T, sm, lane, yi, t, ep.ngen, nullptr);
+        if (cell < 0) { ep.status = EG_EP_NO_LOCATION; return; }   // actions.rs:77-89 is unreachable here (Q16)
+        if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; return; }
+        if (lane == 0) {
+          sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
+          sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
+          gen_cell[ep.ngen] = (uint16_t)cell;
+          gen_pack[ep.ngen] = (uint16_t)(t | (yi << 4) | (m << 9));
+        }
+        __syncthreads();
+        ep.ngen += 1;
+        const double* cc = T.cc + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2;
+        a.gcost += cc[0];
+        if (yi > 0) a.gcost_prev += T.cc[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2];
+        a.co2 += T.co2_t[t];
+        const double out = T.out_mw[t];
+        const int cls = T.cls[t];
+        if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
+        a.optot += (T.m03[cell] + T.t12[(size_t)yi * kTypes + t]) + cc[1];
+        a.opcnt += 1;
+      } else if (action < kFirstOther) {
+        const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
+        if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; return; }
+        const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9));
+        if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
+        __syncthreads();
+        ep.noff += 1;
+        a.offs += T.offv[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
+        a.ocost += T.offc[((size_t)yi * kOffsetTypes + ot) * kMults + m];
+        if (yi > 0) a.ocost_prev += T.offc[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
+      }
+      // 57..59 carry an empty generator id (core.rs:117-119): the lookup fails, nothing changes.  60: DoNothing.
+    };
+    auto push_run = [&](int action) {
+      if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; return; }
+      if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
+      ep.run_pos += 1; ep.n_run_y += 1;
+    };
+    auto push_def = [&](int action) {
+      if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 256) { ep.status = EG_EP_OVERFLOW; return; }
+      if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
+      ep.def_pos += 1; ep.n_def_y += 1;
+    };
+
+    int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
+
+    // ---- deficit repair (simulation.rs:137-141, :319-522) ----
+    const State year_start = state_of(a);
+    if (year_start.balance < 0.0) {
+      const State initial = year_start;
+      double remaining = -year_start.balance;
+      uint32_t attempts = 0;
+      while (remaining > 0.0 && ep.status == EG_EP_OK) {
+        attempts += 1;
+        int action;
+        if (attempts < 5u) {
+          if (replay) {   // sampling.rs:242-313
+            if (S.has_best_deficit) {
+              const int lo = S.bestd_off[yi], n = S.bestd_off[yi + 1] - lo;
+              if (replay_def_idx < n) { action = S.bestd_actions[lo + replay_def_idx]; replay_def_idx += 1; }
+              else action = smart_deficit_fallback(rng, sm, lane);
+            } else action = smart_deficit_fallback(rng, sm, lane);
+            push_def(action);
+          } else action = sample_deficit_weighted(S, rng, sm, lane);
+        } else action = 3 * kBattery;   // simulation.rs:369-376
+        if (attempts > 100000u) { ep.status = EG_EP_OVERFLOW; break; }
+        if (action < kFirstOffset) {
+          const State cur = state_of(a);
+          apply(action);
+          if (ep.status != EG_EP_OK) break;
+          push_def(action); push_run(action);   // simulation.rs:406-409
+          const State nxt = state_of(a);
+          const double overall = evaluate_impact(cur, nxt);
+          const double em = nxt.net < cur.net ? (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0) : 0.0;
+          double ci = 0.0;
+          if (nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; ci = -cost_change / dmax(dabs(cur.cost), 1.0); }
+          const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
+          const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
+          update_deficit_weights(S, sm, lane, action, combined);
+          update_weights(S, sm, lane, action, overall * 0.5);
+          remaining = -dmin(nxt.balance, 0.0);
+        }
+      }
+      if (ep.status == EG_EP_OK) {
+        const State fin = state_of(a);
+        const double success = evaluate_impact(initial, fin);
+        if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
+          const double factor = 0.1 * success;
+          __syncthreads();
+          for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, sm, lane, sm.ydef[i], factor);
+        }
+      }
+    }
+    if (ep.status != EG_EP_OK) break;
+
+    // ---- additional actions (simulation.rs:144-198) ----
+    uint32_t n_add = 0;
+    if (replay) {
+      n_add = S.has_best_actions ? (uint32_t)(S.best_off[yi + 1] - S.best_off[yi]) : 0u;
+    } else {   // sampling.rs:380-443
+      const uint32_t dcount = (uint32_t)ep.n_def_y;
+      const uint32_t cap = dcount >= 20u ? 0u : 20u - dcount;
+      if (cap > 0u) {
+        const double u = rng_f64(rng, sm, lane);
+        if (S.cw != nullptr) {
+          const double* cw = S.cw + yi * EG_N_COUNTS;
+          double total = 0.0;
+          for (int c = 0; c < EG_N_COUNTS; ++c) total += cw[c];
+          if (total > 0.0) {
+            double v = u * total;
+            n_add = 5u < cap ? 5u : cap;
+            for (uint32_t c = 0; c < (uint32_t)EG_N_COUNTS; ++c) { v -= cw[c]; if (v <= 0.0) { n_add = c < cap ? c : cap; break; } }
+          }
+        } else {   // heuristic branch; min/max actions were evaluated on the host (sampling.rs:425-427)
+          const uint32_t hi = S.heur_max < cap ? S.heur_max : cap;
+          const uint32_t lo = S.heur_min < hi ? S.heur_min : hi;
+          n_add = lo == hi ? lo : lo + rng_range32(rng, sm, lane, hi - lo + 1u);
+        }
+      }
+    }
+    for (uint32_t k = 0; k < n_add && ep.status == EG_EP_OK; ++k) {
+      int action;
+      if (replay) {   // sampling.rs:78-145
+        if (S.has_best_actions) {
+          const int lo = S.best_off[yi], n = S.best_off[yi + 1] - lo;
+          if (replay_idx < n) { action = S.best_actions[lo + replay_idx]; replay_idx += 1; }
+          else action = smart_fallback(rng, sm, lane, year);
+        } else action = smart_fallback(rng, sm, lane, year);
+        push_run(action);
+      } else action = sample_action_weighted(S, rng, sm, lane);
+      apply(action);
+      if (ep.status != EG_EP_OK) break;
+      if (ep.act_pos >= EG_ACT_CAP) { ep.status = EG_EP_OVERFLOW; break; }
+      if (lane == 0) act_log[ep.act_pos] = (uint8_t)action;
+      ep.act_pos += 1; ep.n_act_y += 1;
+      push_run(action);   // simulation.rs:197
+    }
+    if (ep.status != EG_EP_OK) break;
+    ep.bytes += 2.0 * (double)(ep.n_act_y + ep.n_def_y);
+
+    // ---- yearly metrics (metrics_calculation.rs:32-175) ----
+    const State s = state_of(a);
+    const double gen = (a.tg + a.ig) + a.sg;
+    const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * T.carbon_price[yi];
+    const double total_capital = a.gcost + a.ocost;
+    const double yearly_capital = yi == 0 ? total_capital : total_capital - (a.gcost_prev + a.ocost_prev);
+    double sales = 0.0;
+    if (S.enable_energy_sales && s.balance > 0.0) { const double gwh = s.balance * 8.76; sales = gwh * 50000.0; }
+    const double yearly_total = yearly_capital + 0.0 + 0.0 - credit - (S.enable_energy_sales ? sales : 0.0);
+    total_cost = yi == 0 ? yearly_total : total_cost + yearly_total;
+    total_credit = yi == 0 ? credit : total_credit + credit;
+    total_sales = yi == 0 ? sales : total_sales + sales;
+    if (S.write_yearly && O.yearly != nullptr) {
+      double v = 0.0;
+      switch (lane) {
+        case EG_Y_YEAR: v = (double)year; break;
+        case EG_Y_POP: v = T.population[yi]; break;
+        case EG_Y_USAGE: v = a.usage; break;
+        case EG_Y_GEN: v = gen; break;
+        case EG_Y_BALANCE: v = s.balance; break;
+        case EG_Y_OPINION: v = s.opinion; break;
+        case EG_Y_YEARLY_CAPITAL: v = yearly_capital; break;
+        case EG_Y_TOTAL_CAPITAL: v = total_capital; break;
+        case EG_Y_INFLATION: v = T.inflation[yi]; break;
+        case EG_Y_CO2: v = a.co2; break;
+        case EG_Y_OFFSET: v = a.offs; break;
+        case EG_Y_NET_CO2: v = s.net; break;
+        case EG_Y_YEARLY_CREDIT: v = credit; break;
+        case EG_Y_TOTAL_CREDIT: v = total_credit; break;
+        case EG_Y_YEARLY_SALES: v = sales; break;
+        case EG_Y_TOTAL_SALES: v = total_sales; break;
+        case EG_Y_ACTIVE_GENS: v = (double)a.opcnt; break;
+        case EG_Y_YEARLY_TOTAL_COST: v = yearly_total; break;
+        case EG_Y_TOTAL_COST: v = total_cost; break;
+        default: v = 0.0; break;   // upgrade / closure costs are identically 0 (simulation.rs:41-42)
+      }
+      if (lane < EG_YEARLY_FIELDS) O.yearly[((size_t)e * kYears + yi) * EG_YEARLY_FIELDS + lane] = v;
+    }
+    if (lane == 0) {
+      O.n_run[(size_t)e * kYears + yi] = ep.n_run_y;
+      O.n_def[(size_t)e * kYears + yi] = ep.n_def_y;
+      O.n_act[(size_t)e * kYears + yi] = ep.n_act_y;
+    }
+    gcost_end = a.gcost; ocost_end = a.ocost;
+    last_net = s.net; last_opinion = s.opinion; last_capital = total_capital; last_balance = s.balance;
+  }
+
+  if (lane == 0) {   // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
+    O.metrics[(size_t)e * 4 + 0] = last_net;
+    O.metrics[(size_t)e * 4 + 1] = last_opinion;
+    O.metrics[(size_t)e * 4 + 2] = last_capital;
+    O.metrics[(size_t)e * 4 + 3] = last_balance >= 0.0 ? 1.0 : 0.0;
+    O.status[e] = ep.status;
+    O.n_gens[e] = ep.ngen;
+    O.n_offsets[e] = ep.noff;
+    O.n_draws[e] = rng.words;
+    O.bytes_moved[e] = ep.bytes;
+  }
+}
+
+// ---- B2: a single placement search, for parity tests of the arg-max --------------------------------------------
+__global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, const uint16_t* __restrict__ cells,
+                                                 int n_extra, int32_t* out_cell, double* out_score) {
+  __shared__ Smem sm;
+  const int lane = threadIdx.x;
+  for (int g = lane; g < n_extra; g += kWave) sm.gcell[g] = cells[g];
+  __syncthreads();
+  double score = 0.0;
+  const int cell = place_search(T, sm, lane, yi, type, n_extra, &score);
+  if (lane == 0) { *out_cell = cell; *out_score = score; }
+}
+
+// ---- reduced-mode update statistics: counts of every (year, action) in the run / deficit lists of a batch -----
+// layout of d_stats: [0] episodes, [1] best score numerator placeholder ... see eg_api.cpp
+__global__ void k_update_stats(DevOut O, uint32_t n, double* stats) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  if (O.status[e] != EG_EP_OK) { atomicAdd(&stats[1], 1.0); return; }
+  atomicAdd(&stats[0], 1.0);
+  const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
+  const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
+  int rp = 0, dp = 0;
+  double* run_cnt = stats + 8;
+  double* def_cnt = stats + 8 + 2 * EG_YEARS * EG_N_ACTIONS;
+  for (int y = 0; y < EG_YEARS; ++y) {
+    const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
+    for (int i = 0; i < nr; ++i) atomicAdd(&run_cnt[y * EG_N_ACTIONS + run[rp + i]], 1.0);
+    for (int i = 0; i < nd; ++i) {
+      const int a = def[dp + i];
+      const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
+      if (slot >= 0) atomicAdd(&def_cnt[y * EG_N_DEFICIT + slot], 1.0);
+    }
+    rp += nr; dp += nd;
+  }
+}
+
+}  // namespace
+
+int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
+                   uint32_t n, const uint8_t* d_replay_mask, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_rollout, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
+                     (unsigned long long)first_index, n, d_replay_mask);
+  return (int)hipGetLastError();
+}
+int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
+                 int32_t* d_out_cell, double* d_out_score, void* stream) {
+  hipLaunchKernelGGL(k_place, dim3(1), dim3(kWave), 0, (hipStream_t)stream, t, gen_type, year_index, d_cells, n_extra,
+                     d_out_cell, d_out_score);
+  return (int)hipGetLastError();
+}
+int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, double* d_stats, void* stream) {
+  (void)s;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_update_stats, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, n, d_stats);
+  return (int)hipGetLastError();
+}
+
+}  // namespace eg

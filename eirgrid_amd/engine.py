@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference interface for the rollout hot path, on top of the C ABI.
+
+Names follow the reference: `ActionWeights` (ai/learning/weights/mod.rs:50-107), `run_iteration`
+(core/iteration.rs:10-20), `SimulationMetrics` (ai/metrics/simulation_metrics.rs:5-11), `find_suitable_location`
+(gpu/metal_location_search.rs:96-103).  All compute happens in libeirgrid_hip.so on the GPU; this file only
+marshals numpy buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native as N
+from .world import World
+
+BASE_YEAR, END_YEAR = 2025, 2050
+
+YEARLY_COLUMNS = [
+    "year", "total_population", "total_power_usage", "total_power_generation", "power_balance",
+    "average_public_opinion", "yearly_capital_cost", "total_capital_cost", "inflation_factor", "total_co2_emissions",
+    "total_carbon_offset", "net_co2_emissions", "yearly_carbon_credit_revenue", "total_carbon_credit_revenue",
+    "yearly_energy_sales_revenue", "total_energy_sales_revenue", "active_generators", "yearly_upgrade_costs",
+    "yearly_closure_costs", "yearly_total_cost", "total_cost",
+]
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _world_struct(world: World):
+    keep = [np.ascontiguousarray(world.settlement_x, dtype=np.float64), np.ascontiguousarray(world.settlement_y, dtype=np.float64),
+            np.ascontiguousarray(world.settlement_pop, dtype=np.uint32),
+            np.ascontiguousarray(world.existing_x, dtype=np.float64), np.ascontiguousarray(world.existing_y, dtype=np.float64),
+            np.ascontiguousarray(world.existing_type, dtype=np.int32), np.ascontiguousarray(world.existing_capacity, dtype=np.float64),
+            np.ascontiguousarray(world.coast_x, dtype=np.float64), np.ascontiguousarray(world.coast_y, dtype=np.float64)]
+    w = N.EgWorld(len(keep[0]), _p(keep[0], C.c_double), _p(keep[1], C.c_double), _p(keep[2], C.c_uint32),
+                  len(keep[3]), _p(keep[3], C.c_double), _p(keep[4], C.c_double), _p(keep[5], C.c_int32), _p(keep[6], C.c_double),
+                  len(keep[7]), _p(keep[7], C.c_double), _p(keep[8], C.c_double), int(world.existing_operational_at_start))
+    return w, keep
+
+
+class HostTables:
+    """The policy-independent tables the library builds on the host for a world (no device needed)."""
+
+    def __init__(self, world: World):
+        w, self._keep = _world_struct(world)
+        self.h = N.lib().eg_host_tables_create(C.byref(w))
+        if not self.h:
+            raise N.EirgridError(N.lib().eg_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            N.lib().eg_host_tables_free(self.h)
+            self.h = None
+
+    def f64(self, name: str) -> np.ndarray:
+        ptr, n = C.POINTER(C.c_double)(), C.c_int64()
+        N.check(N.lib().eg_host_tables_f64(self.h, name.encode(), C.byref(ptr), C.byref(n)), "eg_host_tables_f64")
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def i32(self, name: str) -> np.ndarray:
+        ptr, n = C.POINTER(C.c_int32)(), C.c_int64()
+        N.check(N.lib().eg_host_tables_i32(self.h, name.encode(), C.byref(ptr), C.byref(n)), "eg_host_tables_i32")
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
+class ActionWeights:
+    """ActionWeights held by the library (eg_policy): tables, best strategy, counters."""
+    SC = dict(learning_rate=0, exploration_rate=1, iterations_without_improvement=2, iteration_count=3, has_best=4,
+              best_net_emissions=5, best_opinion=6, best_cost=7, best_reliability=8, has_best_actions=9,
+              has_best_deficit_actions=10, has_count_weights=11)
+
+    def __init__(self):
+        self.h = N.lib().eg_policy_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            N.lib().eg_policy_free(self.h)
+            self.h = None
+
+    def tables(self):
+        w = np.zeros((N.YEARS, N.N_ACTIONS)); dw = np.zeros((N.YEARS, N.N_DEFICIT)); cw = np.zeros((N.YEARS, N.N_COUNTS))
+        N.check(N.lib().eg_policy_get_tables(self.h, _p(w, C.c_double), _p(dw, C.c_double), _p(cw, C.c_double)))
+        return w, dw, cw
+
+    def set_tables(self, w=None, dw=None, cw=None):
+        args, keep = [], []
+        for a in (w, dw, cw):
+            if a is None:
+                args.append(None)
+            else:
+                a = np.ascontiguousarray(a, dtype=np.float64); keep.append(a); args.append(_p(a, C.c_double))
+        N.check(N.lib().eg_policy_set_tables(self.h, *args))
+
+    def get(self, name: str) -> float:
+        return N.lib().eg_policy_get_scalar(self.h, self.SC[name])
+
+    def set(self, name: str, v) -> None:
+        N.check(N.lib().eg_policy_set_scalar(self.h, self.SC[name], float(v)))
+
+    def get_list(self, which: int, yi: int):
+        buf = (C.c_uint8 * 4096)()
+        n = N.lib().eg_policy_get_list(self.h, which, yi, buf, 4096)
+        return list(buf[:n])
+
+    def lists(self, which: int):
+        return [self.get_list(which, y) for y in range(N.YEARS)]
+
+    def snapshot(self) -> N.EgPolicySnapshot:
+        s = N.EgPolicySnapshot()
+        N.check(N.lib().eg_policy_snapshot_view(self.h, C.byref(s)))
+        return s
+
+    def apply_episode(self, metrics, n_run, run_log, n_def, def_log, noise_seed: int = 0):
+        """core/multi_simulation.rs:494-508 for one finished episode."""
+        m = np.ascontiguousarray(metrics, dtype=np.float64)
+        nr = np.ascontiguousarray(n_run, dtype=np.int32); nd = np.ascontiguousarray(n_def, dtype=np.int32)
+        rl = np.ascontiguousarray(run_log, dtype=np.uint8); dl = np.ascontiguousarray(def_log, dtype=np.uint8)
+        N.check(N.lib().eg_policy_apply_episode(self.h, _p(m, C.c_double), _p(nr, C.c_int32), _p(rl, C.c_uint8),
+                                                _p(nd, C.c_int32), _p(dl, C.c_uint8), C.c_uint64(noise_seed)))
+
+
+def score_metrics(metrics, cost_only: bool = False) -> float:
+    m = np.ascontiguousarray(metrics, dtype=np.float64)
+    return N.lib().eg_score_metrics(_p(m, C.c_double), int(cost_only))
+
+
+@dataclass
+class BatchResult:
+    metrics: np.ndarray       # [n,4] final_net_emissions, average_public_opinion, total_cost, power_reliability
+    yearly: np.ndarray        # [n,26,21]
+    status: np.ndarray
+    n_run: np.ndarray; n_def: np.ndarray; n_act: np.ndarray
+    run_log: np.ndarray; def_log: np.ndarray; act_log: np.ndarray
+    n_gens: np.ndarray; gen_cell: np.ndarray; gen_pack: np.ndarray
+    n_offsets: np.ndarray; off_pack: np.ndarray
+    n_draws: np.ndarray; bytes_moved: np.ndarray
+
+    @staticmethod
+    def alloc(n: int) -> "BatchResult":
+        z = np.zeros
+        return BatchResult(z((n, 4)), z((n, N.YEARS, N.YEARLY_FIELDS)), z(n, np.int32), z((n, N.YEARS), np.int32),
+                           z((n, N.YEARS), np.int32), z((n, N.YEARS), np.int32), z((n, N.RUN_CAP), np.uint8),
+                           z((n, N.DEF_CAP), np.uint8), z((n, N.ACT_CAP), np.uint8), z(n, np.int32),
+                           z((n, N.MAX_GENS), np.uint16), z((n, N.MAX_GENS), np.uint16), z(n, np.int32),
+                           z((n, N.MAX_OFFSETS), np.uint16), z(n, np.uint64), z(n))
+
+    def struct(self) -> N.EgEpisodeOut:
+        return N.EgEpisodeOut(_p(self.metrics, C.c_double), _p(self.yearly, C.c_double), _p(self.status, C.c_int32),
+                              _p(self.n_run, C.c_int32), _p(self.n_def, C.c_int32), _p(self.n_act, C.c_int32),
+                              _p(self.run_log, C.c_uint8), _p(self.def_log, C.c_uint8), _p(self.act_log, C.c_uint8),
+                              _p(self.n_gens, C.c_int32), _p(self.gen_cell, C.c_uint16), _p(self.gen_pack, C.c_uint16),
+                              _p(self.n_offsets, C.c_int32), _p(self.off_pack, C.c_uint16), _p(self.n_draws, C.c_uint64),
+                              _p(self.bytes_moved, C.c_double))
+
+    def lists(self, e: int, which: str):
+        log = {"run": self.run_log, "def": self.def_log, "act": self.act_log}[which][e]
+        cnt = {"run": self.n_run, "def": self.n_def, "act": self.n_act}[which][e]
+        out, pos = [], 0
+        for c in cnt:
+            out.append(log[pos:pos + c].tolist()); pos += int(c)
+        return out
+
+
+class Engine:
+    """One eg_ctx: a world resident in the HBM of one MI355X."""
+
+    def __init__(self, world: World, device: int = 0):
+        L = N.lib()
+        if L.eg_device_count() <= 0:
+            raise N.EirgridError("no HIP device visible: eirgrid_amd runs on MI355X (gfx950) only and has no CPU path")
+        w, self._keep = _world_struct(world)
+        self.h = L.eg_create(device, C.byref(w))
+        if not self.h:
+            raise N.EirgridError(L.eg_last_error().decode())
+        self.world = world
+
+    def close(self):
+        if getattr(self, "h", None):
+            N.lib().eg_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _opts(enable_energy_sales=True, enable_construction_delays=False, write_yearly=True):
+        return N.EgOpts(int(enable_energy_sales), int(enable_construction_delays), int(write_yearly))
+
+    def rollout_batch(self, weights: ActionWeights, seed: int, n_episodes: int, first_episode_index: int = 0,
+                      replay_mask=None, enable_energy_sales=True, enable_construction_delays=False,
+                      write_yearly=True) -> BatchResult:
+        """Batched `run_iteration` (core/iteration.rs:10-20): episodes first..first+n against one weights snapshot."""
+        res = BatchResult.alloc(n_episodes)
+        snap = weights.snapshot()
+        opts = self._opts(enable_energy_sales, enable_construction_delays, write_yearly)
+        mask = None
+        if replay_mask is not None:
+            self._mask = np.ascontiguousarray(replay_mask, dtype=np.uint8)
+            assert self._mask.shape == (n_episodes,)
+            mask = _p(self._mask, C.c_uint8)
+        out = res.struct()
+        N.check(N.lib().eg_rollout_batch(self.h, C.byref(snap), C.byref(opts), C.c_uint64(seed & (2**64 - 1)),
+                                         C.c_uint64(first_episode_index), n_episodes, mask, C.byref(out)), "eg_rollout_batch")
+        return res
+
+    def run_iteration(self, iteration: int, weights: ActionWeights, replay_best_strategy: bool, seed: int,
+                      enable_energy_sales: bool = True, enable_construction_delays: bool = False) -> BatchResult:
+        """Single-episode form with the reference's argument order (core/iteration.rs:10-20)."""
+        mask = np.array([1 if replay_best_strategy else 0], dtype=np.uint8)
+        return self.rollout_batch(weights, seed, 1, iteration, mask, enable_energy_sales, enable_construction_delays)
+
+    # device-resident path used by bench.py
+    def upload_snapshot(self, weights: ActionWeights, enable_energy_sales=True, write_yearly=True):
+        snap = weights.snapshot()
+        opts = self._opts(enable_energy_sales, False, write_yearly)
+        N.check(N.lib().eg_upload_snapshot(self.h, C.byref(snap), C.byref(opts)), "eg_upload_snapshot")
+
+    def launch(self, seed: int, first_episode_index: int, n_episodes: int, replay_mask=None):
+        mask = None
+        if replay_mask is not None:
+            self._mask = np.ascontiguousarray(replay_mask, dtype=np.uint8)
+            mask = _p(self._mask, C.c_uint8)
+        N.check(N.lib().eg_rollout_launch(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index),
+                                          n_episodes, mask), "eg_rollout_launch")
+
+    def sync(self):
+        N.check(N.lib().eg_sync(self.h), "eg_sync")
+
+    def fetch(self, n_episodes: int) -> BatchResult:
+        res = BatchResult.alloc(n_episodes)
+        out = res.struct()
+        N.check(N.lib().eg_fetch(self.h, C.byref(out)), "eg_fetch")
+        return res
+
+    def timing_reset(self):
+        N.check(N.lib().eg_timing_reset(self.h))
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int32()
+        N.check(N.lib().eg_timing_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def update_stats(self, d_stats_ptr: int):
+        N.check(N.lib().eg_update_stats(self.h, C.c_void_p(d_stats_ptr)), "eg_update_stats")
+
+    def find_suitable_location(self, gen_type: int, year_index: int = 0, extra_cells=()):
+        """gpu/metal_location_search.rs:96-103 on the device: returns (cell or -1, best score)."""
+        cells = np.ascontiguousarray(list(extra_cells), dtype=np.uint16)
+        cell, score = C.c_int32(), C.c_double()
+        N.check(N.lib().eg_place(self.h, gen_type, year_index, _p(cells, C.c_uint16) if len(cells) else None, len(cells),
+                                 C.byref(cell), C.byref(score)), "eg_place")
+        return cell.value, score.value

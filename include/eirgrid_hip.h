@@ -1,0 +1,194 @@
+/*
+ * eirgrid_hip.h — C ABI of the MI355X-native rollout engine (libeirgrid_hip.so).
+ *
+ * Drop-in boundary for the hot path of ETM-Code/eirgrid's aiSimulator.  The reference has no FFI of its own;
+ * each entry point below names the Rust item it replaces (paths relative to aiSimulator/src/):
+ *
+ *   eg_create / eg_destroy      Map::new + initialize_map              utils/map_handler.rs:351-399, main.rs:74-193
+ *   eg_rollout_batch            run_iteration, batched over episodes   core/iteration.rs:10-20 (callers:
+ *                                                                       core/multi_simulation.rs:472, :690)
+ *   eg_place                    MetalLocationSearch::find_suitable_location   gpu/metal_location_search.rs:96-103
+ *   eg_policy_*                 ActionWeights::{new, update_*, apply_*}        ai/learning/weights/ (all files)
+ *   eg_policy_apply_episode     the write-locked section               core/multi_simulation.rs:494-508
+ *
+ * Conventions: plain pointers and sizes, caller-allocated host buffers unless a parameter is named d_* (device
+ * pointer).  Every function returning int32_t returns EG_OK (0) or a negative EG_ERR_* code; eg_last_error()
+ * gives the text.  One eg_ctx per device; a ctx is not thread-safe, independent ctxs may be used from separate
+ * host threads.  The library fails loudly (EG_ERR_NO_DEVICE) when no HIP device is present: there is no CPU
+ * fallback behind this ABI.
+ *
+ * Canonical action indices (the reference walks std::HashMap in hash order; this ABI fixes the insertion order
+ * of ActionWeights::new, ai/learning/weights/core.rs:35-120):
+ *   0..44   AddGenerator(type = idx/3 in models/generator.rs:11-36 order, cost multiplier {100,120,150}[idx%3])
+ *   45..56  AddCarbonOffset({Forest, Wetland, ActiveCapture, CarbonCredit}[(idx-45)/3], {100,120,150}[(idx-45)%3])
+ *   57 UpgradeEfficiency("")   58 AdjustOperation("",0)   59 CloseGenerator("")   60 DoNothing
+ * Deficit table (core.rs:130-152): GasPeaker, GasCombinedCycle, BatteryStorage, PumpedStorage, Biomass,
+ *   OnshoreWind, OffshoreWind, UtilitySolar, HydroDam, Nuclear, DomesticSolar, CommercialSolar, TidalGenerator,
+ *   WaveEnergy, DoNothing.
+ */
+#ifndef EIRGRID_HIP_H
+#define EIRGRID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG_YEARS 26
+#define EG_N_ACTIONS 61
+#define EG_N_DEFICIT 15
+#define EG_N_COUNTS 21
+#define EG_N_TYPES 15
+#define EG_GRID 51
+#define EG_CELLS (EG_GRID * EG_GRID)
+#define EG_YEARLY_FIELDS 21
+
+/* per-episode capacities of the device logs (an episode that exceeds one ends with status EG_EP_OVERFLOW) */
+#define EG_MAX_GENS 1024
+#define EG_MAX_OFFSETS 1024
+#define EG_RUN_CAP 2048
+#define EG_DEF_CAP 1024
+#define EG_ACT_CAP 1024
+
+#define EG_OK 0
+#define EG_ERR_NO_DEVICE (-1)
+#define EG_ERR_BAD_ARG (-2)
+#define EG_ERR_HIP (-3)
+#define EG_ERR_UNSUPPORTED (-4)
+#define EG_ERR_NOMEM (-5)
+
+#define EG_EP_OK 0
+#define EG_EP_OVERFLOW (-1)
+#define EG_EP_NO_LOCATION (-2)
+
+/* yearly row columns: the scalar fields of YearlyMetrics, analysis/metrics.rs:7-31 */
+enum {
+  EG_Y_YEAR = 0, EG_Y_POP, EG_Y_USAGE, EG_Y_GEN, EG_Y_BALANCE, EG_Y_OPINION, EG_Y_YEARLY_CAPITAL,
+  EG_Y_TOTAL_CAPITAL, EG_Y_INFLATION, EG_Y_CO2, EG_Y_OFFSET, EG_Y_NET_CO2, EG_Y_YEARLY_CREDIT, EG_Y_TOTAL_CREDIT,
+  EG_Y_YEARLY_SALES, EG_Y_TOTAL_SALES, EG_Y_ACTIVE_GENS, EG_Y_UPGRADE_COSTS, EG_Y_CLOSURE_COSTS,
+  EG_Y_YEARLY_TOTAL_COST, EG_Y_TOTAL_COST
+};
+
+typedef struct eg_ctx eg_ctx;
+typedef struct eg_policy eg_policy;
+
+/* What initialize_map loads (main.rs:74-193): settlements.json, ireland_generators.csv, coastline_points.json. */
+typedef struct {
+  int32_t n_settlements;
+  const double *settlement_x, *settlement_y;   /* grid metres, clamped to [0, 50000] like data/poi.rs:11-15 */
+  const uint32_t *settlement_pop;              /* 2025 population */
+  int32_t n_existing;
+  const double *existing_x, *existing_y;
+  const int32_t *existing_type;                /* generator type index */
+  const double *existing_capacity_mw;          /* CSV capacity_mw (data/generators_loader.rs:150-153) */
+  int32_t n_coast;
+  const double *coast_x, *coast_y;
+  int32_t existing_operational_at_start;       /* 0 = reference HEAD: existing plant starts "Planned" in 2024 */
+} eg_world;
+
+/* Flags that reach run_simulation (core/simulation.rs:22-31; cli/cli.rs:42-55). */
+typedef struct {
+  int32_t enable_energy_sales;          /* CLI default true */
+  int32_t enable_construction_delays;   /* CLI default false; true is not implemented on the device yet */
+  int32_t write_yearly;                 /* 1: fill eg_episode_out.yearly */
+} eg_opts;
+
+/* Read-only view of ActionWeights for one batch (ai/learning/weights/mod.rs:50-107). */
+typedef struct {
+  const double *weights;          /* [26][61] */
+  const double *deficit_weights;  /* [26][15] */
+  const double *count_weights;    /* [26][21], NULL = absent (dropped by the checkpoint loader) */
+  double learning_rate, exploration_rate;
+  uint32_t iterations_without_improvement;
+  int32_t has_best;
+  double best_metrics[4];         /* final_net_emissions, average_public_opinion, total_cost, power_reliability */
+  /* replay data (best_actions / best_deficit_actions), flat year-major; NULL when has_best == 0 */
+  const int32_t *best_count;          /* [26] */
+  const uint8_t *best_actions;        /* sum(best_count) */
+  const int32_t *best_deficit_count;  /* [26] */
+  const uint8_t *best_deficit_actions;
+} eg_policy_snapshot;
+
+/* Host-side result buffers, episode-major.  Any pointer may be NULL (that output is skipped). */
+typedef struct {
+  double *metrics;      /* [n][4]  SimulationMetrics, core/iteration.rs:69-74 */
+  double *yearly;       /* [n][26][21] */
+  int32_t *status;      /* [n] EG_EP_* */
+  int32_t *n_run;       /* [n][26] current_run_actions per year */
+  int32_t *n_def;       /* [n][26] current_deficit_actions per year */
+  int32_t *n_act;       /* [n][26] SimulationResult.actions per year */
+  uint8_t *run_log;     /* [n][EG_RUN_CAP] flat, year-major */
+  uint8_t *def_log;     /* [n][EG_DEF_CAP] */
+  uint8_t *act_log;     /* [n][EG_ACT_CAP] */
+  int32_t *n_gens;      /* [n] */
+  uint16_t *gen_cell;   /* [n][EG_MAX_GENS] placement result: i*51+j on the 1 km grid */
+  uint16_t *gen_pack;   /* [n][EG_MAX_GENS] type | build-year index << 4 | multiplier index << 9 */
+  int32_t *n_offsets;   /* [n] */
+  uint16_t *off_pack;   /* [n][EG_MAX_OFFSETS] offset type | year index << 4 | multiplier index << 9 */
+  uint64_t *n_draws;    /* [n] words consumed from the episode stream */
+  double *bytes_moved;  /* [n] algorithmic bytes of the episode, SURVEY.md §8(d) formula */
+} eg_episode_out;
+
+const char *eg_last_error(void);
+int32_t eg_device_count(void);
+
+eg_ctx *eg_create(int32_t device_ordinal, const eg_world *world);
+void eg_destroy(eg_ctx *);
+
+/* Run episodes [first_episode_index, first_episode_index + n) against one snapshot.  Episode e draws from
+ * StdRng::seed_from_u64(seed + e) (the reference gives every episode the same stream under --seed,
+ * core/simulation.rs:50-53; e = 0 reproduces that).  replay_mask[i] != 0 runs episode i with
+ * replay_best_strategy = true (core/multi_simulation.rs:461-465).  Results are copied into `out`. */
+int32_t eg_rollout_batch(eg_ctx *, const eg_policy_snapshot *, const eg_opts *, uint64_t seed,
+                         uint64_t first_episode_index, uint32_t n_episodes, const uint8_t *replay_mask,
+                         eg_episode_out *out);
+
+/* Device-resident variant for the timed path: upload the snapshot once, launch any number of batches (results
+ * stay in HBM), then fetch the last batch. */
+int32_t eg_upload_snapshot(eg_ctx *, const eg_policy_snapshot *, const eg_opts *);
+int32_t eg_rollout_launch(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes,
+                          const uint8_t *replay_mask /* host, may be NULL */);
+int32_t eg_sync(eg_ctx *);
+int32_t eg_fetch(eg_ctx *, eg_episode_out *out);
+/* HIP-event time of the rollout kernel launches since the last call to eg_timing_reset (milliseconds, count). */
+int32_t eg_timing_reset(eg_ctx *);
+int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
+/* Per-batch update statistics of the last launched batch, reduced on the device into `d_stats`
+ * (EG_STATS_LEN doubles, device pointer — e.g. a torch tensor that is then all-reduced over RCCL). */
+#define EG_STATS_LEN (8 + 2 * EG_YEARS * EG_N_ACTIONS + 2 * EG_YEARS * EG_N_DEFICIT)
+int32_t eg_update_stats(eg_ctx *, double *d_stats);
+
+/* B2: one placement search on the device (settlements of year index `year_index`, the ctx's existing plant plus
+ * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */
+int32_t eg_place(eg_ctx *, int32_t gen_type, int32_t year_index, const uint16_t *extra_cells, int32_t n_extra,
+                 int32_t *out_cell, double *out_score);
+
+/* ---- policy-independent host tables (built once per world; no device needed), read-only views for validation.
+ * Names: usage population pre_co2 pre_tg pre_ig pre_sg pre_optot te coastf dr m03 t12 cc out_mw co2_t offv offc
+ * inflation carbon_price size_factor (f64); pre_opcnt cls rclass marine reach existing_online (i32). ---- */
+typedef struct eg_host_tables eg_host_tables;
+eg_host_tables *eg_host_tables_create(const eg_world *world);
+void eg_host_tables_free(eg_host_tables *);
+int32_t eg_host_tables_f64(const eg_host_tables *, const char *name, const double **ptr, int64_t *len);
+int32_t eg_host_tables_i32(const eg_host_tables *, const char *name, const int32_t **ptr, int64_t *len);
+
+/* ---- ActionWeights on the host (C++ mirror of ai/learning/weights/) ---- */
+eg_policy *eg_policy_new(void);                                     /* core.rs:25-250 */
+void eg_policy_free(eg_policy *);
+int32_t eg_policy_snapshot_view(const eg_policy *, eg_policy_snapshot *out);  /* pointers live as long as the policy */
+int32_t eg_policy_get_tables(const eg_policy *, double *w, double *dw, double *cw);
+int32_t eg_policy_set_tables(eg_policy *, const double *w, const double *dw, const double *cw);
+double eg_policy_get_scalar(const eg_policy *, int32_t which);     /* same codes as the oracle: see eg_policy.cpp */
+int32_t eg_policy_set_scalar(eg_policy *, int32_t which, double v);
+int32_t eg_policy_get_list(const eg_policy *, int32_t which, int32_t year_index, uint8_t *out, int32_t cap);
+/* multi_simulation.rs:494-508 for one episode: transfer_recorded_actions_from → apply_contrast_learning →
+ * update_best_strategy → apply_deficit_contrast_learning.  run/def lists are flat year-major with counts. */
+int32_t eg_policy_apply_episode(eg_policy *, const double metrics[4], const int32_t *n_run, const uint8_t *run_log,
+                                const int32_t *n_def, const uint8_t *def_log, uint64_t noise_seed);
+double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

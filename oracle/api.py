@@ -53,6 +53,15 @@ class EpisodeOut(C.Structure):
     ]
 
 
+class Tables(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_double)) for n in ("usage", "population", "pre_co2", "pre_tg", "pre_ig", "pre_sg", "pre_optot")] + \
+               [("pre_opcnt", C.POINTER(C.c_int32))] + \
+               [(n, C.POINTER(C.c_double)) for n in ("te", "coastf", "dr")] + [("size_factor", C.c_double)] + \
+               [(n, C.POINTER(C.c_double)) for n in ("m03", "t12", "cc", "out_mw", "co2_t")] + \
+               [(n, C.POINTER(C.c_int32)) for n in ("cls", "rclass", "marine", "reach")] + \
+               [(n, C.POINTER(C.c_double)) for n in ("offv", "offc", "inflation", "carbon_price")] + [("n_existing", C.c_int32)]
+
+
 _lib = None
 
 
@@ -87,6 +96,8 @@ def lib():
     L.og_weights_get_best_weights.argtypes = [C.c_void_p, dp]
     L.og_run_episode.restype = C.c_int32
     L.og_run_episode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(EpisodeOut)]
+    L.og_run_episode_tabled.restype = C.c_int32
+    L.og_run_episode_tabled.argtypes = [C.POINTER(Tables), C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(EpisodeOut)]
     L.og_post_episode_update.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_uint64]
     L.og_score_metrics.restype = C.c_double
     L.og_score_metrics.argtypes = [dp, C.c_int32]
@@ -221,6 +232,34 @@ def run_episode(world: OracleWorld, weights: OracleWeights, seed: int, replay: b
     out = EpisodeOut()
     st = lib().og_run_episode(world.h, weights.h, int(replay), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(energy_sales),
                               int(delays), C.byref(out))
+    return st, out
+
+
+class OracleTables:
+    """Tables for the oracle's tabled mode.  `source` provides f64(name)/i32(name) arrays — in the tests that is the
+    product library's eg_host_tables view, so running the tabled mode validates those tables."""
+    F64 = ("usage", "population", "pre_co2", "pre_tg", "pre_ig", "pre_sg", "pre_optot", "te", "coastf", "dr", "m03", "t12",
+           "cc", "out_mw", "co2_t", "offv", "offc", "inflation", "carbon_price")
+    I32 = ("pre_opcnt", "cls", "rclass", "marine", "reach")
+
+    def __init__(self, source, n_existing):
+        self.arrays = {}
+        t = Tables()
+        for n in self.F64:
+            a = np.ascontiguousarray(source.f64(n), dtype=np.float64); self.arrays[n] = a
+            setattr(t, n, a.ctypes.data_as(C.POINTER(C.c_double)))
+        for n in self.I32:
+            a = np.ascontiguousarray(source.i32(n), dtype=np.int32); self.arrays[n] = a
+            setattr(t, n, a.ctypes.data_as(C.POINTER(C.c_int32)))
+        t.size_factor = float(source.f64("size_factor")[0])
+        t.n_existing = int(n_existing)
+        self.t = t
+
+
+def run_episode_tabled(tables: OracleTables, weights: OracleWeights, seed: int, replay: bool = False, energy_sales: bool = True):
+    out = EpisodeOut()
+    st = lib().og_run_episode_tabled(C.byref(tables.t), weights.h, int(replay), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+                                     int(energy_sales), C.byref(out))
     return st, out
 
 

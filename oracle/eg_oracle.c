@@ -51,7 +51,7 @@ static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v >
 static double maxd(double a, double b) { return a > b ? a : b; } /* f64::max, no NaNs on this path */
 static double mind(double a, double b) { return a < b ? a : b; }
 /* f64::round = half away from zero (simulation.rs:112, Q12) */
-static double round_half_away(double v) { return v < 0.0 ? -floor(-v + 0.5) : floor(v + 0.5); }
+static double round_half_away(double v) { return round(v); }
 
 /* ------------------------------------------------------------------------- */
 /* per-type formulas (models/generator.rs)                                    */
@@ -1293,4 +1293,196 @@ int32_t og_place(const og_world *w, int32_t yi, int32_t type, int32_t n_extra, c
   if (best_score) *best_score = score;
   free(extra); map_free(&m);
   return found ? cell_of(loc) : -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* tabled mode                                                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  double co2, tg, ig, sg, optot, gcost, ocost, gcost_prev, ocost_prev, offs, usage; int opcnt;
+} agg_t;
+typedef struct { int cell, type, year, mult; } tgen_t;
+typedef struct { int type, year, mult; } toff_t;
+typedef struct {
+  const og_tables *T; tgen_t *gens; int ngens; toff_t *offs; int noffs; agg_t a; int yi; double *fld;
+} tmap_t;
+
+static action_result tstate(const agg_t *a) {
+  action_result r;
+  r.net_emissions = a->co2 - a->offs;
+  r.public_opinion = a->opcnt > 0 ? a->optot / (double)a->opcnt : 1.0;
+  r.power_balance = ((a->tg + a->ig) + a->sg) - a->usage;
+  r.total_cost = a->gcost + a->ocost;
+  return r;
+}
+static const double *cc_at(const og_tables *T, int yi, int t, int b, int m) {
+  return T->cc + ((((size_t)yi * OG_NTYPES + (size_t)t) * OG_YEARS + (size_t)b) * 3 + (size_t)m) * 2;
+}
+static int tplace(tmap_t *m, int t) {
+  const og_tables *T = m->T;
+  int rc = T->rclass[t], reach = T->reach[rc];
+  const double *te = T->te + ((size_t)m->yi * 6 + (size_t)rc) * 2601;
+  const double *dr = T->dr + (size_t)rc * 169;
+  for (int c = 0; c < 2601; ++c) m->fld[c] = te[c];
+  for (int g = 0; g < m->ngens; ++g) {
+    int gi = m->gens[g].cell / 51, gj = m->gens[g].cell % 51;
+    for (int di = -reach; di <= reach; ++di) for (int dj = -reach; dj <= reach; ++dj) {
+      int ci = gi + di, cj = gj + dj;
+      if (ci < 0 || ci > 50 || cj < 0 || cj > 50) continue;
+      m->fld[ci * 51 + cj] *= dr[(di < 0 ? -di : di) * 13 + (dj < 0 ? -dj : dj)];
+    }
+  }
+  double best = 0.0; int best_c = -1;
+  for (int c = 0; c < 2601; ++c) {
+    double s = m->fld[c];
+    if (T->marine[t]) s *= T->coastf[c];
+    s *= T->size_factor;
+    if (s > best) { best = s; best_c = c; }
+  }
+  return best_c;
+}
+static void tapply(tmap_t *m, int action, rec_t *rec) {
+  const og_tables *T = m->T; agg_t *a = &m->a; int yi = m->yi;
+  og_episode_out *o = rec->out;
+  if (is_add_generator(action)) {
+    int t = action / 3, mi = action % 3;
+    int cell = tplace(m, t);
+    if (cell < 0) { rec->overflow = 2; return; }
+    if (m->ngens >= OG_LOG_CAP) { rec->overflow = 1; return; }
+    tgen_t g = {cell, t, yi, mi}; m->gens[m->ngens++] = g;
+    o->gen_cell[o->n_gens] = (uint16_t)cell; o->gen_type[o->n_gens] = (uint8_t)t; o->gen_year[o->n_gens] = (uint8_t)yi;
+    o->gen_mult[o->n_gens] = (uint8_t)mi; o->n_gens++;
+    const double *cc = cc_at(T, yi, t, yi, mi);
+    a->gcost += cc[0];
+    if (yi > 0) a->gcost_prev += cc_at(T, yi - 1, t, yi, mi)[0];
+    a->co2 += T->co2_t[t];
+    if (T->cls[t] == 1) a->ig += T->out_mw[t]; else if (T->cls[t] == 2) a->sg += T->out_mw[t]; else a->tg += T->out_mw[t];
+    a->optot += (T->m03[cell] + T->t12[(size_t)yi * OG_NTYPES + (size_t)t]) + cc[1];
+    a->opcnt += 1;
+  } else if (action < OG_A_UPGRADE) {
+    int ot = (action - 45) / 3, mi = (action - 45) % 3;
+    if (m->noffs >= OG_LOG_CAP) { rec->overflow = 1; return; }
+    toff_t f = {ot, yi, mi}; m->offs[m->noffs++] = f;
+    o->off_type[o->n_offsets] = (uint8_t)ot; o->off_year[o->n_offsets] = (uint8_t)yi; o->off_mult[o->n_offsets] = (uint8_t)mi; o->n_offsets++;
+    a->offs += T->offv[((size_t)yi * 4 + (size_t)ot) * OG_YEARS + (size_t)yi];
+    a->ocost += T->offc[((size_t)yi * 4 + (size_t)ot) * 3 + (size_t)mi];
+    if (yi > 0) a->ocost_prev += T->offc[((size_t)(yi - 1) * 4 + (size_t)ot) * 3 + (size_t)mi];
+  }
+}
+static void thandle_power_deficit(tmap_t *m, og_weights *p, rec_t *rec) {
+  int yi = m->yi;
+  action_result initial_state = tstate(&m->a);
+  double remaining = -initial_state.power_balance;
+  uint32_t attempts = 0;
+  while (remaining > 0.0) {
+    attempts += 1;
+    int action = attempts < 5 ? sample_deficit_action(p, yi) : 3 * T_BATTERY;
+    action_result current_state = tstate(&m->a);
+    if (is_add_generator(action)) {
+      tapply(m, action, rec);
+      if (rec->overflow) return;
+      list_push(&p->cur_def[yi], (uint8_t)action);
+      list_push(&p->cur_run[yi], (uint8_t)action);
+      action_result new_state = tstate(&m->a);
+      double overall = evaluate_impact(&current_state, &new_state);
+      double emissions_improvement = new_state.net_emissions < current_state.net_emissions
+        ? (current_state.net_emissions - new_state.net_emissions) / maxd(fabs(current_state.net_emissions), 1.0) : 0.0;
+      double cost_improvement = 0.0;
+      if (new_state.net_emissions < 1000.0) {
+        double cost_change = new_state.total_cost - current_state.total_cost;
+        cost_improvement = -cost_change / maxd(fabs(current_state.total_cost), 1.0);
+      }
+      double opinion_improvement = new_state.total_cost < MAX_ACCEPTABLE_COST * 8.0
+        ? (new_state.public_opinion - current_state.public_opinion) / maxd(1.0 - current_state.public_opinion, 0.1) : 0.0;
+      double combined = overall * 0.7 + emissions_improvement * 0.15 + cost_improvement * 0.1 + opinion_improvement * 0.05;
+      update_deficit_weights(p, action, yi, combined);
+      update_weights(p, action, yi, overall * 0.5);
+      remaining = -mind(new_state.power_balance, 0.0);
+    }
+    if (attempts > 100000u) { rec->overflow = 1; return; }
+  }
+  action_result final_state = tstate(&m->a);
+  double overall_success = evaluate_impact(&initial_state, &final_state);
+  if (final_state.power_balance >= 0.0 && overall_success > 0.0 && p->cur_def[yi].n > 0) {
+    double success_factor = 0.1 * overall_success;
+    list_t snapshot = {0, 0, 0}; list_copy(&snapshot, &p->cur_def[yi]);
+    for (int i = 0; i < snapshot.n; ++i) update_deficit_weights(p, snapshot.a[i], yi, success_factor);
+    free(snapshot.a);
+  }
+}
+int32_t og_run_episode_tabled(const og_tables *T, og_weights *p, int32_t replay, uint64_t seed, int32_t enable_energy_sales,
+                              og_episode_out *out) {
+  memset(out, 0, sizeof(*out));
+  rec_t rec = {out, 0};
+  tmap_t m; memset(&m, 0, sizeof(m));
+  m.T = T; m.gens = (tgen_t *)malloc(sizeof(tgen_t) * OG_LOG_CAP); m.offs = (toff_t *)malloc(sizeof(toff_t) * OG_LOG_CAP);
+  m.fld = (double *)malloc(sizeof(double) * 2601);
+  for (int y = 0; y < OG_YEARS; ++y) { list_clear(&p->cur_run[y]); list_clear(&p->cur_def[y]); p->replay_idx[y] = 0; p->replay_def_idx[y] = 0; }
+  p->force_best = replay ? 1 : 0;
+  rng_seed(&p->rng, seed); p->has_rng = 1;
+  double gcost_end = 0.0, ocost_end = 0.0;
+  for (int yi = 0; yi < OG_YEARS && !rec.overflow; ++yi) {
+    int year = OG_BASE_YEAR + yi; m.yi = yi;
+    agg_t *a = &m.a;
+    a->co2 = T->pre_co2[yi]; a->tg = T->pre_tg[yi]; a->ig = T->pre_ig[yi]; a->sg = T->pre_sg[yi];
+    a->optot = T->pre_optot[yi]; a->opcnt = T->pre_opcnt[yi]; a->usage = T->usage[yi];
+    a->gcost = 0.0; a->ocost = 0.0; a->offs = 0.0; a->gcost_prev = gcost_end; a->ocost_prev = ocost_end;
+    for (int g = 0; g < m.ngens; ++g) {
+      const tgen_t *G = &m.gens[g];
+      const double *cc = cc_at(T, yi, G->type, G->year, G->mult);
+      a->gcost += cc[0]; a->co2 += T->co2_t[G->type];
+      if (T->cls[G->type] == 1) a->ig += T->out_mw[G->type]; else if (T->cls[G->type] == 2) a->sg += T->out_mw[G->type]; else a->tg += T->out_mw[G->type];
+      a->optot += (T->m03[G->cell] + T->t12[(size_t)yi * OG_NTYPES + (size_t)G->type]) + cc[1];
+      a->opcnt += 1;
+    }
+    for (int k = 0; k < m.noffs; ++k) {
+      const toff_t *F = &m.offs[k];
+      a->offs += T->offv[((size_t)yi * 4 + (size_t)F->type) * OG_YEARS + (size_t)F->year];
+      a->ocost += T->offc[((size_t)yi * 4 + (size_t)F->type) * 3 + (size_t)F->mult];
+    }
+    action_result s0 = tstate(a);
+    if (s0.power_balance < 0.0) thandle_power_deficit(&m, p, &rec);
+    if (rec.overflow) break;
+    uint32_t n_additional;
+    if (p->force_best) n_additional = p->has_best_actions ? (uint32_t)p->best_actions[yi].n : 0;
+    else n_additional = sample_additional_actions(p, yi);
+    for (uint32_t k = 0; k < n_additional && !rec.overflow; ++k) {
+      int action = sample_action(p, yi);
+      tapply(&m, action, &rec);
+      log_push(out->act_log, out->n_act, yi, action, &rec);
+      list_push(&p->cur_run[yi], (uint8_t)action);
+    }
+    if (rec.overflow) break;
+    action_result s = tstate(a);
+    double *row = out->yearly[yi]; const double *prev = yi > 0 ? out->yearly[yi - 1] : 0;
+    double gen = (a->tg + a->ig) + a->sg;
+    double credit = s.net_emissions >= 0.0 ? 0.0 : (-s.net_emissions) * T->carbon_price[yi];
+    double total_capital = a->gcost + a->ocost;
+    double yearly_capital = yi == 0 ? total_capital : total_capital - (a->gcost_prev + a->ocost_prev);
+    double sales = 0.0;
+    if (enable_energy_sales && s.power_balance > 0.0) { double gwh = s.power_balance * 8.76; sales = gwh * 50000.0; }
+    double yearly_total = yearly_capital + 0.0 + 0.0 - credit - (enable_energy_sales ? sales : 0.0);
+    row[OG_Y_YEAR] = (double)year; row[OG_Y_POP] = T->population[yi]; row[OG_Y_USAGE] = a->usage; row[OG_Y_GEN] = gen;
+    row[OG_Y_BALANCE] = s.power_balance; row[OG_Y_OPINION] = s.public_opinion; row[OG_Y_YEARLY_CAPITAL] = yearly_capital;
+    row[OG_Y_TOTAL_CAPITAL] = total_capital; row[OG_Y_INFLATION] = T->inflation[yi]; row[OG_Y_CO2] = a->co2; row[OG_Y_OFFSET] = a->offs;
+    row[OG_Y_NET_CO2] = s.net_emissions; row[OG_Y_YEARLY_CREDIT] = credit;
+    row[OG_Y_TOTAL_CREDIT] = prev ? prev[OG_Y_TOTAL_CREDIT] + credit : credit;
+    row[OG_Y_YEARLY_SALES] = sales; row[OG_Y_TOTAL_SALES] = prev ? prev[OG_Y_TOTAL_SALES] + sales : sales;
+    row[OG_Y_ACTIVE_GENS] = (double)a->opcnt; row[OG_Y_UPGRADE_COSTS] = 0.0; row[OG_Y_CLOSURE_COSTS] = 0.0;
+    row[OG_Y_YEARLY_TOTAL_COST] = yearly_total; row[OG_Y_TOTAL_COST] = prev ? prev[OG_Y_TOTAL_COST] + yearly_total : yearly_total;
+    gcost_end = a->gcost; ocost_end = a->ocost;
+  }
+  const double *last = out->yearly[OG_YEARS - 1];
+  out->metrics[0] = last[OG_Y_NET_CO2]; out->metrics[1] = last[OG_Y_OPINION]; out->metrics[2] = last[OG_Y_TOTAL_CAPITAL];
+  out->metrics[3] = last[OG_Y_BALANCE] >= 0.0 ? 1.0 : 0.0;
+  int pr = 0, pd = 0;
+  for (int y = 0; y < OG_YEARS; ++y) {
+    out->n_run[y] = p->cur_run[y].n; out->n_def[y] = p->cur_def[y].n;
+    for (int i = 0; i < p->cur_run[y].n; ++i) { if (pr < OG_LOG_CAP) out->run_log[pr++] = p->cur_run[y].a[i]; else rec.overflow = 1; }
+    for (int i = 0; i < p->cur_def[y].n; ++i) { if (pd < OG_LOG_CAP) out->def_log[pd++] = p->cur_def[y].a[i]; else rec.overflow = 1; }
+  }
+  out->n_draws = p->rng.words;
+  out->status = rec.overflow ? -rec.overflow : 0;
+  free(m.gens); free(m.offs); free(m.fld);
+  return out->status;
 }

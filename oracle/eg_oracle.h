@@ -114,6 +114,23 @@ int32_t og_run_episode(const og_world *, og_weights *weights, int32_t replay_bes
 void og_post_episode_update(og_weights *shared, const og_weights *local, const double metrics[4],
                             uint64_t noise_seed);
 
+/* ---- "tabled" mode: the same episode evaluated from policy-independent tables (per-year settlement-term table,
+ * memoised opinion/cost terms, incrementally maintained aggregates).  The tables are INPUTS here — the tests pass in
+ * the ones the product library builds (eg_host_tables_*), which is how they are validated against the literal mode
+ * above on a machine without a GPU.  Also the CPU baseline that does not credit the GPU with memoisation. ---- */
+typedef struct {
+  const double *usage, *population, *pre_co2, *pre_tg, *pre_ig, *pre_sg, *pre_optot;
+  const int32_t *pre_opcnt;
+  const double *te, *coastf, *dr;
+  double size_factor;
+  const double *m03, *t12, *cc, *out_mw, *co2_t;
+  const int32_t *cls, *rclass, *marine, *reach;
+  const double *offv, *offc, *inflation, *carbon_price;
+  int32_t n_existing;
+} og_tables;
+int32_t og_run_episode_tabled(const og_tables *, og_weights *weights, int32_t replay_best_strategy, uint64_t seed,
+                              int32_t enable_energy_sales, og_episode_out *out);
+
 /* ---- pure formula KATs ---- */
 double og_score_metrics(const double metrics[4], int32_t cost_only);                 /* ai/metrics/scoring.rs:5-45 */
 double og_evaluate_action_impact(const double cur[4], const double nxt[4], int32_t cost_only); /* scoring.rs:46-85 */
