@@ -11,7 +11,7 @@ import os
 YEARS, N_ACTIONS, N_DEFICIT, N_COUNTS, N_TYPES = 26, 61, 15, 21, 15
 GRID, CELLS, YEARLY_FIELDS = 51, 2601, 21
 MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 1024, 1024, 2048, 1024, 1024
-STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + 2 * YEARS * N_DEFICIT
+STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
 
 EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -53,7 +53,8 @@ class EgEpisodeOut(C.Structure):
 # every symbol include/eirgrid_hip.h declares
 EXPORTS = [
     "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
-    "eg_rollout_launch", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_place",
+    "eg_rollout_launch", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
+    "eg_fetch_episode_lists", "eg_place", "eg_policy_apply_reduced",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
     "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
@@ -92,6 +93,12 @@ def lib():
     L.eg_timing_read.argtypes = [C.c_void_p, _dp, _i32p]
     L.eg_update_stats.restype = C.c_int32
     L.eg_update_stats.argtypes = [C.c_void_p, C.c_void_p]
+    L.eg_fetch_scores.restype = C.c_int32
+    L.eg_fetch_scores.argtypes = [C.c_void_p, _dp]
+    L.eg_fetch_episode_lists.restype = C.c_int32
+    L.eg_fetch_episode_lists.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, _u8p, _i32p, _u8p]
+    L.eg_policy_apply_reduced.restype = C.c_int32
+    L.eg_policy_apply_reduced.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _dp, _i32p, _u8p, _i32p, _u8p, C.c_uint64]
     L.eg_place.restype = C.c_int32
     L.eg_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u16p, C.c_int32, _i32p, _dp]
     L.eg_host_tables_create.restype = C.c_void_p

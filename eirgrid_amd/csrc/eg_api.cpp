@@ -55,6 +55,8 @@ struct eg_ctx {
   double *d_w = nullptr, *d_dw = nullptr, *d_cw = nullptr;
   int32_t *d_best_off = nullptr, *d_bestd_off = nullptr;
   uint8_t *d_best = nullptr, *d_bestd = nullptr;
+  unsigned long long *d_best_mask = nullptr, *d_bestd_mask = nullptr;
+  StatsParams stats_params{};
   size_t best_cap = 0, bestd_cap = 0;
   DevSnapshot snap{};
   bool snap_valid = false;
@@ -84,7 +86,7 @@ int upload_vec(eg_ctx* c, const std::vector<T>& v, const T** dst) {
 void free_outputs(eg_ctx* c) {
   void* ptrs[] = {c->out.metrics, c->out.yearly, c->out.status, c->out.n_run, c->out.n_def, c->out.n_act, c->out.run_log,
                   c->out.def_log, c->out.act_log, c->out.n_gens, c->out.gen_cell, c->out.gen_pack, c->out.n_offsets,
-                  c->out.off_pack, c->out.n_draws, c->out.bytes_moved};
+                  c->out.off_pack, c->out.n_draws, c->out.bytes_moved, c->out.score};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   c->out = DevOut{}; c->out_cap = 0;
 }
@@ -109,6 +111,7 @@ int ensure_outputs(eg_ctx* c, uint32_t n) {
   EG_HIP(hipMalloc((void**)&c->out.off_pack, N * EG_MAX_OFFSETS * sizeof(uint16_t)));
   EG_HIP(hipMalloc((void**)&c->out.n_draws, N * sizeof(unsigned long long)));
   EG_HIP(hipMalloc((void**)&c->out.bytes_moved, N * sizeof(double)));
+  EG_HIP(hipMalloc((void**)&c->out.score, N * sizeof(double)));
   // zero the year-count tables once so episodes that end early leave defined data behind
   EG_HIP(hipMemset(c->out.n_run, 0, N * EG_YEARS * sizeof(int32_t)));
   EG_HIP(hipMemset(c->out.n_def, 0, N * EG_YEARS * sizeof(int32_t)));
@@ -166,7 +169,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     size_t wb = sizeof(double) * EG_YEARS * EG_N_ACTIONS, db = sizeof(double) * EG_YEARS * EG_N_DEFICIT, cb = sizeof(double) * EG_YEARS * EG_N_COUNTS;
     if (hipMalloc((void**)&c->d_w, wb) != hipSuccess || hipMalloc((void**)&c->d_dw, db) != hipSuccess ||
         hipMalloc((void**)&c->d_cw, cb) != hipSuccess || hipMalloc((void**)&c->d_best_off, 27 * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_bestd_off, 27 * sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP; }
+        hipMalloc((void**)&c->d_bestd_off, 27 * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->d_best_mask, 26 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_bestd_mask, 26 * sizeof(unsigned long long)) != hipSuccess) { set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP; }
   }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
@@ -177,7 +182,7 @@ void eg_destroy(eg_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
-  void* snap[] = {c->d_w, c->d_dw, c->d_cw, c->d_best_off, c->d_bestd_off, c->d_best, c->d_bestd, c->d_mask};
+  void* snap[] = {c->d_w, c->d_dw, c->d_cw, c->d_best_off, c->d_bestd_off, c->d_best, c->d_bestd, c->d_mask, c->d_best_mask, c->d_bestd_mask};
   for (void* p : snap) if (p) (void)hipFree(p);
   free_outputs(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -245,6 +250,25 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   rc = put(&c->d_bestd, &c->bestd_cap, have_lists ? s->best_deficit_actions : nullptr, have_lists ? size_t(offd[26]) : 0);
   if (rc != EG_OK) return rc;
   S.best_off = c->d_best_off; S.best_actions = c->d_best; S.bestd_off = c->d_bestd_off; S.bestd_actions = c->d_bestd;
+  unsigned long long mask[26] = {0}, dmask[26] = {0};
+  if (have_lists)
+    for (int y = 0; y < EG_YEARS; ++y) {
+      for (int i = off[y]; i < off[y + 1]; ++i) if (s->best_actions[i] < 64) mask[y] |= 1ull << s->best_actions[i];
+      for (int i = offd[y]; i < offd[y + 1]; ++i) if (s->best_deficit_actions[i] < 64) { mask[y] |= 1ull << s->best_deficit_actions[i]; dmask[y] |= 1ull << s->best_deficit_actions[i]; }
+    }
+  EG_HIP(hipMemcpy(c->d_best_mask, mask, sizeof(mask), hipMemcpyHostToDevice));
+  EG_HIP(hipMemcpy(c->d_bestd_mask, dmask, sizeof(dmask), hipMemcpyHostToDevice));
+  S.best_mask = c->d_best_mask; S.bestd_mask = c->d_bestd_mask;
+  {  // learning.rs:134-180: everything of the contrast step that depends only on the snapshot
+    StatsParams& P = c->stats_params;
+    const double k = double(s->iterations_without_improvement);
+    P.has_best = have_lists ? 1 : 0;
+    P.best_score = s->has_best ? eg_score_metrics(s->best_metrics, 0) : 0.0;
+    P.threshold = 0.1 * std::fmax(std::exp(-k / 500.0), 0.00001 / 0.1);
+    P.forced = s->iterations_without_improvement > 800u ? 1 : 0;
+    P.stagnation = 1.0 + (0.2 * std::pow(k / 10.0, 1.8));
+    P.adaptive_lr = s->learning_rate * (1.0 + 0.1 * k);
+  }
   S.enable_energy_sales = o ? (o->enable_energy_sales ? 1 : 0) : 1;
   S.write_yearly = o ? (o->write_yearly ? 1 : 0) : 1;
   c->snap_valid = true;
@@ -323,12 +347,31 @@ int32_t eg_timing_read(eg_ctx* c, double* total_ms, int32_t* n_launches) {
   return rc;
 }
 
-int32_t eg_update_stats(eg_ctx* c, double* d_stats) {
-  if (!c || !d_stats) return EG_ERR_BAD_ARG;
+int32_t eg_update_stats(eg_ctx* c, int64_t* d_stats) {
+  if (!c || !d_stats || !c->snap_valid) { set_error("eg_update_stats: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  EG_HIP(hipMemsetAsync(d_stats, 0, sizeof(double) * EG_STATS_LEN, nullptr));
-  int lr = launch_update_stats(c->snap, c->out, c->last_n, d_stats, nullptr);
+  EG_HIP(hipMemsetAsync(d_stats, 0, sizeof(int64_t) * EG_STATS_LEN, nullptr));
+  int lr = launch_update_stats(c->snap, c->out, c->stats_params, c->last_n, (long long*)d_stats, nullptr);
   if (lr != 0) { set_error(std::string("k_update_stats launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  return EG_OK;
+}
+
+int32_t eg_fetch_scores(eg_ctx* c, double* scores) {
+  if (!c || !scores) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  if (c->last_n) EG_HIP(hipMemcpy(scores, c->out.score, sizeof(double) * c->last_n, hipMemcpyDeviceToHost));
+  return EG_OK;
+}
+
+int32_t eg_fetch_episode_lists(eg_ctx* c, uint32_t i, double metrics[4], int32_t* n_run, uint8_t* run_log, int32_t* n_def,
+                               uint8_t* def_log) {
+  if (!c || i >= c->last_n || !metrics || !n_run || !run_log || !n_def || !def_log) { set_error("eg_fetch_episode_lists: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipMemcpy(metrics, c->out.metrics + size_t(i) * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(n_run, c->out.n_run + size_t(i) * EG_YEARS, EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(n_def, c->out.n_def + size_t(i) * EG_YEARS, EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(run_log, c->out.run_log + size_t(i) * EG_RUN_CAP, EG_RUN_CAP, hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(def_log, c->out.def_log + size_t(i) * EG_DEF_CAP, EG_DEF_CAP, hipMemcpyDeviceToHost));
   return EG_OK;
 }
 

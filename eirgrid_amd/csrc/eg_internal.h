@@ -84,6 +84,8 @@ struct DevSnapshot {
   const uint8_t* best_actions;
   const int32_t* bestd_off;    // [27]
   const uint8_t* bestd_actions;
+  const unsigned long long* best_mask;   // [26] bit a set: action a occurs in best_actions[y] or best_deficit_actions[y]
+  const unsigned long long* bestd_mask;  // [26] bit a set: action a occurs in best_deficit_actions[y]
   int32_t enable_energy_sales;
   int32_t write_yearly;
 };
@@ -96,6 +98,7 @@ struct DevOut {
   int32_t* n_gens; uint16_t* gen_cell; uint16_t* gen_pack;
   int32_t* n_offsets; uint16_t* off_pack;
   unsigned long long* n_draws; double* bytes_moved;
+  double* score;   // written by k_update_stats
 };
 
 void set_error(const std::string& s);
@@ -105,6 +108,15 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
                    uint32_t n, const uint8_t* d_replay_mask, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
-int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, double* d_stats, void* stream);
+// scalars of the contrast step that depend only on the snapshot (learning.rs:131-180), evaluated on the host
+struct StatsParams {
+  double best_score;     // score_metrics(best_metrics)
+  int32_t has_best;      // best metrics and best action lists present
+  double threshold;      // dynamic threshold, learning.rs:146-154
+  int32_t forced;        // iterations_without_improvement > 800
+  double adaptive_lr;    // learning.rs:174
+  double stagnation;     // learning.rs:163-164
+};
+int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream);
 
 }  // namespace eg

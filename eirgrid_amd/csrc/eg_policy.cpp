@@ -271,4 +271,76 @@ int32_t eg_policy_apply_episode(eg_policy* p, const double metrics[4], const int
   return EG_OK;
 }
 
+// Batch form of the three steps above ("reduced mode").  All episodes of the batch were sampled from
+// the same snapshot, so they are all contrasted against the best strategy of that snapshot; their multiplicative
+// nudges were summed in log space on the device (Q32 integers) and are applied once, with the clamps applied after
+// accumulation.  Then the batch's best episode competes for the best slot, then the deficit table is contrasted with
+// the stall counter that results — the same order as multi_simulation.rs:494-508.
+int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double cand_metrics[4], const int32_t* cand_n_run,
+                                const uint8_t* cand_run_log, const int32_t* cand_n_def, const uint8_t* cand_def_log,
+                                uint64_t noise_seed) {
+  if (!p || !stats) return EG_ERR_BAD_ARG;
+  HostRng noise(noise_seed);
+  const int64_t n_ok = stats[0], n_qual = stats[2];
+  const int64_t* pen = stats + 8; const int64_t* mild = stats + 8 + Y * NA; const int64_t* dcnt = stats + 8 + 2 * Y * NA;
+  auto clampw = [](double v) { return v < kMinW ? kMinW : (v > kMaxW ? kMaxW : v); };
+  auto randomize = [&](double* row, int n) {
+    for (int i = 0; i < n; ++i) row[i] = clampw(row[i] * (1.0 + 0.25 * (noise.next_f64() * 2.0 - 1.0)));
+  };
+  if (p->has_best && p->has_best_actions && n_qual > 0) {   // apply_contrast_learning
+    const double k = double(p->stall);
+    const double stagnation_factor = 1.0 + (0.2 * std::pow(k / 10.0, 1.8));
+    const double adaptive_lr = p->learning_rate * (1.0 + 0.1 * k);
+    const double ln_boost = std::log(1.0 + (adaptive_lr * 2.0 * stagnation_factor));
+    for (int y = 0; y < Y; ++y) {
+      int occ[NA] = {0};
+      for (uint8_t a : p->best_actions[y]) occ[a] += 1;
+      if (p->has_best_deficit) for (uint8_t a : p->best_deficit[y]) occ[a] += 1;
+      for (int a = 0; a < NA; ++a) {
+        const double L = double(n_qual) * double(occ[a]) * ln_boost + (double(pen[y * NA + a]) + double(mild[y * NA + a])) / 4294967296.0;
+        if (L != 0.0) p->w[y][a] = clampw(p->w[y][a] * std::exp(L));
+      }
+    }
+    if (p->stall > 1200) for (int y = 0; y < Y; ++y) randomize(p->w[y].data(), NA);
+  }
+  // update_best_strategy with the batch's candidate
+  p->iteration_count += uint32_t(n_ok);
+  bool improved = false;
+  if (cand_metrics && cand_n_run && cand_n_def && n_ok > 0)
+    improved = !p->has_best || eg_score_metrics(cand_metrics, 0) > eg_score_metrics(p->best_metrics.data(), 0);
+  if (improved) {
+    p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = cand_metrics[i];
+    p->has_best_weights = true; p->best_w = p->w;
+    for (int y = 0, rp = 0, dp = 0; y < Y; ++y) {
+      p->best_actions[y].assign(cand_run_log + rp, cand_run_log + rp + cand_n_run[y]); rp += cand_n_run[y];
+      p->best_deficit[y].assign(cand_def_log + dp, cand_def_log + dp + cand_n_def[y]); dp += cand_n_def[y];
+      p->cur_run[y] = p->best_actions[y]; p->cur_def[y] = p->best_deficit[y];
+    }
+    p->has_best_actions = true; p->has_best_deficit = true; p->stall = 0;
+  } else p->stall += uint32_t(n_ok);
+  // apply_deficit_contrast_learning: the same factor for every episode (it depends on the stall counter only)
+  if (!improved && p->has_best && p->has_best_deficit) {
+    const double st = double(p->stall);
+    const double deterioration = st / 10.0;
+    const double threshold = 0.05 * std::fmax(std::exp(-st / 400.0), 0.00001 / 0.05);
+    if (deterioration > threshold || p->stall > 800) {
+      const double stagnation_factor = 1.0 + (0.2 * std::pow(st / 10.0, 1.8));
+      const double combined_penalty = std::pow(deterioration, 0.3) * stagnation_factor;
+      const double adaptive_lr = p->learning_rate * (1.0 + 0.1 * st);
+      const double ln_pen = std::log(1.0 / (1.0 + adaptive_lr * 1.5 * combined_penalty));
+      const double ln_boost = std::log(1.0 + (adaptive_lr * 2.0 * stagnation_factor * 1.5));
+      for (int y = 0; y < Y; ++y) {
+        int occ[ND] = {0};
+        for (uint8_t a : p->best_deficit[y]) { const int s = deficit_slot(a); if (s >= 0) occ[s] += 1; }
+        for (int s = 0; s < ND; ++s) {
+          const double L = double(n_ok) * double(occ[s]) * ln_boost + double(dcnt[y * ND + s]) * ln_pen;
+          if (L != 0.0) p->dw[y][s] = clampw(p->dw[y][s] * std::exp(L));
+        }
+      }
+      if (p->stall > 1200) for (int y = 0; y < Y; ++y) randomize(p->dw[y].data(), ND);
+    }
+  }
+  return improved ? 1 : EG_OK;
+}
+
 }  // extern "C"

@@ -577,28 +577,86 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
-// ---- reduced-mode update statistics: counts of every (year, action) in the run / deficit lists of a batch -----
-// layout of d_stats: [0] episodes, [1] best score numerator placeholder ... see eg_api.cpp
-__global__ void k_update_stats(DevOut O, uint32_t n, double* stats) {
+// ---- batch ("reduced") update statistics --------------------------------------------------------------------
+// The reference applies apply_contrast_learning / apply_deficit_contrast_learning one episode at a time under a lock
+// (multi_simulation.rs:494-508).  For a batch that shares one snapshot the same multiplicative nudges are
+// accumulated here in log space, as integers (Q32 fixed point), so the result does not depend on the order in which
+// episodes, workgroups or ranks contribute: one sum all-reduce of this buffer is the whole exchange.
+//   stats[0] episodes ok   [1] episodes failed   [2] episodes that qualify for contrast (learning.rs:160)
+//   stats[8 + (y*61+a)]              Σ Q32 ln(penalty_factor)  over occurrences of a in year y that are absent from best
+//   stats[8 + 26*61 + (y*61+a)]      Σ Q32 ln(mild_penalty)    over right-action-wrong-slot occurrences (learning.rs:241-251)
+//   stats[8 + 2*26*61 + (y*15+s)]    number of deficit actions of slot s in year y absent from best_deficit_actions[y]
+constexpr int kStatsMain = EG_YEARS * EG_N_ACTIONS;
+constexpr int kStatsBins = 2 * kStatsMain + EG_YEARS * EG_N_DEFICIT;
+constexpr double kQ32 = 4294967296.0;
+
+__device__ double device_score(const double* m) {   // ai/metrics/scoring.rs:18-44 (mode None)
+  if (m[0] > 0.0) return 1.0 - dmin(m[0] / 1000000.0, 1.0);
+  const double normalized_cost = dmax(m[2] / kMaxCost, 1.0);
+  const double cost_score = 1.0 - dmin(log(normalized_cost) / log(kMaxCost * 100.0 / kMaxCost), 1.0);
+  const double cost_weight = normalized_cost > 8.0 ? 0.8 : 0.5;
+  return 1.0 + (cost_score * cost_weight + m[1] * (1.0 - cost_weight));
+}
+
+__global__ void __launch_bounds__(256) k_update_stats(DevOut O, DevSnapshot S, StatsParams P, uint32_t n, long long* stats) {
+  __shared__ long long h[kStatsBins];
+  __shared__ long long head[4];
+  for (int i = threadIdx.x; i < kStatsBins; i += blockDim.x) h[i] = 0;
+  if (threadIdx.x < 4) head[threadIdx.x] = 0;
+  __syncthreads();
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  if (O.status[e] != EG_EP_OK) { atomicAdd(&stats[1], 1.0); return; }
-  atomicAdd(&stats[0], 1.0);
-  const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
-  const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
-  int rp = 0, dp = 0;
-  double* run_cnt = stats + 8;
-  double* def_cnt = stats + 8 + 2 * EG_YEARS * EG_N_ACTIONS;
-  for (int y = 0; y < EG_YEARS; ++y) {
-    const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
-    for (int i = 0; i < nr; ++i) atomicAdd(&run_cnt[y * EG_N_ACTIONS + run[rp + i]], 1.0);
-    for (int i = 0; i < nd; ++i) {
-      const int a = def[dp + i];
-      const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
-      if (slot >= 0) atomicAdd(&def_cnt[y * EG_N_DEFICIT + slot], 1.0);
+  if (e < n) {
+    if (O.status[e] != EG_EP_OK) {
+      atomicAdd((unsigned long long*)&head[1], 1ull);
+      O.score[e] = -1.0;
+    } else {
+      atomicAdd((unsigned long long*)&head[0], 1ull);
+      const double score = device_score(O.metrics + (size_t)e * 4);
+      O.score[e] = score;
+      const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
+      const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
+      if (P.has_best) {
+        const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
+        const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
+        long long q_pen = 0, q_mild = 0;
+        if (qualifies) {
+          atomicAdd((unsigned long long*)&head[2], 1ull);
+          const double combined = pow(det, 0.3) * P.stagnation;                        // learning.rs:168-171
+          q_pen = llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);     // learning.rs:177
+          q_mild = llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);    // learning.rs:247
+        }
+        int rp = 0, dp = 0;
+        for (int y = 0; y < EG_YEARS; ++y) {
+          const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
+          if (qualifies) {
+            const unsigned long long mask = S.best_mask[y];
+            const int b0 = S.best_off[y], nb = S.best_off[y + 1] - b0, d0 = S.bestd_off[y], nbd = S.bestd_off[y + 1] - d0;
+            for (int j = 0; j < nr + nd; ++j) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
+              const int a = j < nr ? run[rp + j] : def[dp + (j - nr)];
+              if (!((mask >> a) & 1ull)) atomicAdd((unsigned long long*)&h[y * EG_N_ACTIONS + a], (unsigned long long)q_pen);
+              else if (j < nb + nbd) {
+                const int b = j < nb ? S.best_actions[b0 + j] : S.bestd_actions[d0 + (j - nb)];
+                if (a != b) atomicAdd((unsigned long long*)&h[kStatsMain + y * EG_N_ACTIONS + a], (unsigned long long)q_mild);
+              }
+            }
+          }
+          const unsigned long long dmask = S.bestd_mask[y];
+          for (int j = 0; j < nd; ++j) {   // learning.rs:346-352
+            const int a = def[dp + j];
+            if (!((dmask >> a) & 1ull)) {
+              const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
+              if (slot >= 0) atomicAdd((unsigned long long*)&h[2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
+            }
+          }
+          rp += nr; dp += nd;
+        }
+      }
     }
-    rp += nr; dp += nd;
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kStatsBins; i += blockDim.x)
+    if (h[i] != 0) atomicAdd((unsigned long long*)&stats[8 + i], (unsigned long long)h[i]);
+  if (threadIdx.x < 3 && head[threadIdx.x] != 0) atomicAdd((unsigned long long*)&stats[threadIdx.x], (unsigned long long)head[threadIdx.x]);
 }
 
 }  // namespace
@@ -616,10 +674,9 @@ int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_
                      d_out_cell, d_out_score);
   return (int)hipGetLastError();
 }
-int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, double* d_stats, void* stream) {
-  (void)s;
+int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_update_stats, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, n, d_stats);
+  hipLaunchKernelGGL(k_update_stats, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, s, p, n, d_stats);
   return (int)hipGetLastError();
 }
 

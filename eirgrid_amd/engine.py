@@ -123,6 +123,25 @@ class ActionWeights:
                                                 _p(nd, C.c_int32), _p(dl, C.c_uint8), C.c_uint64(noise_seed)))
 
 
+def apply_reduced(weights: "ActionWeights", stats, candidate, noise_seed: int = 0) -> bool:
+    """Batch form of core/multi_simulation.rs:494-508 (SURVEY.md §8(e) reduced mode).  `stats` is the all-reduced host copy
+    of the eg_update_stats buffer (int64[STATS_LEN]); `candidate` = (metrics, n_run, run_log, n_def, def_log) of the batch's
+    best episode or None.  Returns True when the candidate became the best strategy."""
+    st = np.ascontiguousarray(stats, dtype=np.int64)
+    assert st.shape == (N.STATS_LEN,)
+    if candidate is None:
+        rc = N.lib().eg_policy_apply_reduced(weights.h, _p(st, C.c_int64), None, None, None, None, None, C.c_uint64(noise_seed))
+    else:
+        m = np.ascontiguousarray(candidate[0], dtype=np.float64)
+        nr = np.ascontiguousarray(candidate[1], dtype=np.int32); rl = np.ascontiguousarray(candidate[2], dtype=np.uint8)
+        nd = np.ascontiguousarray(candidate[3], dtype=np.int32); dl = np.ascontiguousarray(candidate[4], dtype=np.uint8)
+        rc = N.lib().eg_policy_apply_reduced(weights.h, _p(st, C.c_int64), _p(m, C.c_double), _p(nr, C.c_int32), _p(rl, C.c_uint8),
+                                             _p(nd, C.c_int32), _p(dl, C.c_uint8), C.c_uint64(noise_seed))
+    if rc < 0:
+        N.check(rc, "eg_policy_apply_reduced")
+    return rc == 1
+
+
 def score_metrics(metrics, cost_only: bool = False) -> float:
     m = np.ascontiguousarray(metrics, dtype=np.float64)
     return N.lib().eg_score_metrics(_p(m, C.c_double), int(cost_only))
@@ -244,7 +263,20 @@ class Engine:
         return ms.value, n.value
 
     def update_stats(self, d_stats_ptr: int):
+        """Reduce the last launched batch into an int64[STATS_LEN] DEVICE buffer (e.g. torch tensor .data_ptr())."""
         N.check(N.lib().eg_update_stats(self.h, C.c_void_p(d_stats_ptr)), "eg_update_stats")
+
+    def fetch_scores(self, n_episodes: int) -> np.ndarray:
+        s = np.zeros(n_episodes)
+        N.check(N.lib().eg_fetch_scores(self.h, _p(s, C.c_double)), "eg_fetch_scores")
+        return s
+
+    def fetch_episode_lists(self, episode: int):
+        m = np.zeros(4); nr = np.zeros(N.YEARS, np.int32); nd = np.zeros(N.YEARS, np.int32)
+        rl = np.zeros(N.RUN_CAP, np.uint8); dl = np.zeros(N.DEF_CAP, np.uint8)
+        N.check(N.lib().eg_fetch_episode_lists(self.h, episode, _p(m, C.c_double), _p(nr, C.c_int32), _p(rl, C.c_uint8),
+                                               _p(nd, C.c_int32), _p(dl, C.c_uint8)), "eg_fetch_episode_lists")
+        return m, nr, rl, nd, dl
 
     def find_suitable_location(self, gen_type: int, year_index: int = 0, extra_cells=()):
         """gpu/metal_location_search.rs:96-103 on the device: returns (cell or -1, best score)."""

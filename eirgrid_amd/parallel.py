@@ -1,0 +1,125 @@
+"""Data-parallel rollout over the GPUs of one node: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).
+
+Episodes are independent given a policy snapshot, so a batch is sharded by global episode index with no data-path
+collective.  The only exchange is the per-update one of SURVEY.md §8(e):
+  * ONE sum all-reduce of the int64 update-statistics buffer (EG_STATS_LEN * 8 B ≈ 28 KB, latency-bound);
+  * best-candidate selection: an all-gather of one (score, global index) pair per rank, then the owner broadcasts the
+    winning episode's metrics + action lists (≈3 KB).
+Every rank then applies the identical update to its own copy of ActionWeights (integer statistics ⇒ bit-identical
+replicas, no weight broadcast).  torch is used for device memory, the stream and the collectives only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native as N
+from .engine import ActionWeights, Engine, apply_reduced
+
+
+def shard_range(total: int, rank: int, world_size: int):
+    """Contiguous shard [first, first+count) of `total` episodes for `rank` (first ranks take the remainder)."""
+    base, rem = divmod(total, world_size)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def pick_candidate(pairs):
+    """pairs: iterable of (score, global_index) per rank (index < 0 = no candidate).  Highest score wins, ties go to the
+    lowest global index.  Returns (rank, score, index) or None."""
+    best = None
+    for r, (s, i) in enumerate(pairs):
+        if i < 0:
+            continue
+        if best is None or s > best[1] or (s == best[1] and i < best[2]):
+            best = (r, float(s), int(i))
+    return best
+
+
+def pack_candidate(metrics, n_run, run_log, n_def, def_log) -> np.ndarray:
+    """Flat uint8 payload of the best-candidate broadcast."""
+    return np.concatenate([np.asarray(metrics, np.float64).view(np.uint8), np.asarray(n_run, np.int32).view(np.uint8),
+                           np.asarray(n_def, np.int32).view(np.uint8), np.asarray(run_log, np.uint8), np.asarray(def_log, np.uint8)])
+
+
+def unpack_candidate(buf: np.ndarray):
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    o = 0
+    m = buf[o:o + 32].view(np.float64).copy(); o += 32
+    nr = buf[o:o + 4 * N.YEARS].view(np.int32).copy(); o += 4 * N.YEARS
+    nd = buf[o:o + 4 * N.YEARS].view(np.int32).copy(); o += 4 * N.YEARS
+    rl = buf[o:o + N.RUN_CAP].copy(); o += N.RUN_CAP
+    dl = buf[o:o + N.DEF_CAP].copy()
+    return m, nr, rl, nd, dl
+
+
+CANDIDATE_BYTES = 32 + 8 * N.YEARS + N.RUN_CAP + N.DEF_CAP
+
+
+def exchange_update(stats, local_pair, local_payload_fn, dist=None, device=None):
+    """The whole per-update exchange.  `stats`: torch int64 tensor [STATS_LEN] (summed in place), `local_pair`:
+    (score, global index) of this rank's best episode (index -1 if none), `local_payload_fn()` → uint8 ndarray
+    [CANDIDATE_BYTES] of that episode (only called on the winning rank).  Returns (stats ndarray, candidate tuple|None).
+    With dist=None (single process) nothing is exchanged."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        cand = unpack_candidate(local_payload_fn()) if local_pair[1] >= 0 else None
+        return stats.cpu().numpy(), cand
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)                         # the one all-reduce of the update
+    pair = torch.tensor([float(local_pair[0]), float(local_pair[1])], dtype=torch.float64, device=device)
+    gathered = [torch.empty_like(pair) for _ in range(ws)]
+    dist.all_gather(gathered, pair)
+    pairs = [(float(g[0]), int(g[1])) for g in torch.stack(gathered).cpu()]
+    win = pick_candidate(pairs)
+    cand = None
+    if win is not None:
+        if rank == win[0]:
+            payload = torch.from_numpy(local_payload_fn()).to(device)
+        else:
+            payload = torch.empty(CANDIDATE_BYTES, dtype=torch.uint8, device=device)
+        dist.broadcast(payload, src=win[0])
+        cand = unpack_candidate(payload.cpu().numpy())
+    return stats.cpu().numpy(), cand
+
+
+class BatchTrainer:
+    """Rollout + batch update loop of one rank (the driver of configs 2-4)."""
+
+    def __init__(self, engine: Engine, weights: ActionWeights, episodes_per_rank: int, seed: int, rank: int = 0,
+                 world_size: int = 1, dist=None, replay_fraction: float = 0.0, write_yearly: bool = True):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.eng, self.w = engine, weights
+        self.n, self.seed, self.rank, self.ws = episodes_per_rank, seed, rank, world_size
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.stats = torch.zeros(N.STATS_LEN, dtype=torch.int64, device=self.device)
+        self.replay_fraction = replay_fraction
+        self.write_yearly = write_yearly
+        self.step_index = 0
+        self.improvements = 0
+
+    def step(self) -> bool:
+        """One pass of the hot path: rollout of this rank's shard, update statistics, the exchange, the update."""
+        total = self.n * self.ws
+        first = self.step_index * total + self.rank * self.n           # global episode index of this shard
+        mask = None
+        if self.replay_fraction > 0.0 and self.w.get("has_best_actions") == 1:
+            period = max(1, int(round(1.0 / self.replay_fraction)))
+            mask = ((np.arange(first, first + self.n) % period) == 0).astype(np.uint8)
+        self.eng.upload_snapshot(self.w, write_yearly=self.write_yearly)
+        self.eng.launch(self.seed, first, self.n, mask)
+        self.eng.update_stats(self.stats.data_ptr())
+        scores = self.eng.fetch_scores(self.n)                          # synchronises with the stream
+        ok = scores >= 0.0
+        if ok.any():
+            best_local = int(np.flatnonzero(scores == scores[ok].max())[0])
+            pair = (float(scores[best_local]), first + best_local)
+        else:
+            best_local, pair = -1, (-1.0, -1)
+        stats, cand = exchange_update(self.stats, pair, lambda: pack_candidate(*self.eng.fetch_episode_lists(best_local)),
+                                      self.dist, self.device)
+        improved = apply_reduced(self.w, stats, cand, noise_seed=self.seed + self.step_index)
+        self.improvements += int(improved)
+        self.step_index += 1
+        return improved

@@ -154,10 +154,21 @@ int32_t eg_fetch(eg_ctx *, eg_episode_out *out);
 /* HIP-event time of the rollout kernel launches since the last call to eg_timing_reset (milliseconds, count). */
 int32_t eg_timing_reset(eg_ctx *);
 int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
-/* Per-batch update statistics of the last launched batch, reduced on the device into `d_stats`
- * (EG_STATS_LEN doubles, device pointer — e.g. a torch tensor that is then all-reduced over RCCL). */
-#define EG_STATS_LEN (8 + 2 * EG_YEARS * EG_N_ACTIONS + 2 * EG_YEARS * EG_N_DEFICIT)
-int32_t eg_update_stats(eg_ctx *, double *d_stats);
+/* Batch ("reduced") form of the write-locked update (core/multi_simulation.rs:494-508).
+ * eg_update_stats reduces the last launched batch on the device into d_stats (EG_STATS_LEN int64, DEVICE pointer, e.g.
+ * a torch tensor): integer sums that do not depend on episode / workgroup / rank order, so ONE sum all-reduce over
+ * RCCL is the whole exchange; eg_policy_apply_reduced then applies them on the host.  Layout:
+ *   [0] episodes ok  [1] episodes failed  [2] episodes that qualify for contrast learning (learning.rs:160)
+ *   [8 + y*61 + a]               sum of Q32 ln(penalty_factor), learning.rs:232-239
+ *   [8 + 26*61 + y*61 + a]       sum of Q32 ln(mild_penalty),   learning.rs:241-251
+ *   [8 + 2*26*61 + y*15 + slot]  deficit actions absent from best_deficit_actions[y], learning.rs:346-352 */
+#define EG_STATS_LEN (8 + 2 * EG_YEARS * EG_N_ACTIONS + EG_YEARS * EG_N_DEFICIT)
+int32_t eg_update_stats(eg_ctx *, int64_t *d_stats);
+/* score_metrics of every episode of the last batch (written by eg_update_stats; -1 for failed episodes) */
+int32_t eg_fetch_scores(eg_ctx *, double *scores);
+/* metrics and action lists of one episode of the last batch (the best-candidate broadcast of SURVEY.md §8(e)) */
+int32_t eg_fetch_episode_lists(eg_ctx *, uint32_t episode, double metrics[4], int32_t *n_run, uint8_t *run_log /* EG_RUN_CAP */,
+                               int32_t *n_def, uint8_t *def_log /* EG_DEF_CAP */);
 
 /* B2: one placement search on the device (settlements of year index `year_index`, the ctx's existing plant plus
  * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */
@@ -186,6 +197,11 @@ int32_t eg_policy_get_list(const eg_policy *, int32_t which, int32_t year_index,
  * update_best_strategy → apply_deficit_contrast_learning.  run/def lists are flat year-major with counts. */
 int32_t eg_policy_apply_episode(eg_policy *, const double metrics[4], const int32_t *n_run, const uint8_t *run_log,
                                 const int32_t *n_def, const uint8_t *def_log, uint64_t noise_seed);
+/* The same three steps for a whole batch that shared one snapshot: `stats` is the (all-reduced) host copy of the
+ * eg_update_stats buffer, the candidate is the batch's best episode (highest score, ties to the lowest global index). */
+int32_t eg_policy_apply_reduced(eg_policy *, const int64_t *stats, const double cand_metrics[4], const int32_t *cand_n_run,
+                                const uint8_t *cand_run_log, const int32_t *cand_n_def, const uint8_t *cand_def_log,
+                                uint64_t noise_seed);
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus

@@ -1,0 +1,120 @@
+"""GPU: the batch update path — statistics kernel vs a numpy restatement, the reduced update, and the trainer loop."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from eirgrid_amd import _native as N
+from eirgrid_amd.engine import ActionWeights, apply_reduced, score_metrics
+from eirgrid_amd.parallel import BatchTrainer
+
+pytestmark = pytest.mark.gpu
+
+DEFICIT_SLOT = {24: 0, 21: 1, 36: 2, 33: 3, 27: 4, 0: 5, 3: 6, 12: 7, 30: 8, 15: 9, 6: 10, 9: 11, 39: 12, 42: 13, 60: 14}
+
+
+def _seed_best(engine):
+    pol = ActionWeights()
+    first = engine.run_iteration(0, pol, False, 12345)
+    pol.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
+                      first.def_log[0, :first.n_def[0].sum()])
+    return pol
+
+
+def _expected_stats(pol, res):
+    """learning.rs:131-255 / :285-352 accumulated over a batch, straight from the definitions."""
+    n = len(res.status)
+    best = [pol.get_list(0, y) for y in range(26)]; bestd = [pol.get_list(1, y) for y in range(26)]
+    s0 = score_metrics([pol.get(k) for k in ("best_net_emissions", "best_opinion", "best_cost", "best_reliability")])
+    k = pol.get("iterations_without_improvement"); lr = pol.get("learning_rate")
+    thr = 0.1 * max(math.exp(-k / 500.0), 1e-4)
+    stag = 1.0 + 0.2 * (k / 10.0) ** 1.8; alr = lr * (1.0 + 0.1 * k)
+    pen = np.zeros((26, 61)); mild = np.zeros((26, 61)); dcnt = np.zeros((26, 15), np.int64); nq = 0
+    scores = np.zeros(n)
+    for e in range(n):
+        s = score_metrics(res.metrics[e]); scores[e] = s
+        det = (s0 - s) / s0 if s0 > 0 else 0.0
+        q = det > thr and det > 0
+        nq += q
+        run, dfl = res.lists(e, "run"), res.lists(e, "def")
+        for y in range(26):
+            cb = best[y] + bestd[y]
+            if q:
+                comb = det ** 0.3 * stag
+                for j, a in enumerate(run[y] + dfl[y]):
+                    if a not in cb:
+                        pen[y, a] += math.log(1.0 / (1.0 + alr * 1.5 * comb))
+                    elif j < len(cb) and a != cb[j]:
+                        mild[y, a] += math.log(1.0 / (1.0 + alr * comb * 0.5))
+            for a in dfl[y]:
+                if a not in bestd[y] and a in DEFICIT_SLOT:
+                    dcnt[y, DEFICIT_SLOT[a]] += 1
+    return scores, nq, pen, mild, dcnt
+
+
+def test_stats_kernel_vs_numpy(engine):
+    pol = _seed_best(engine)
+    n = 512
+    engine.upload_snapshot(pol)
+    engine.launch(999, 0, n)
+    stats = torch.zeros(N.STATS_LEN, dtype=torch.int64, device="cuda")
+    engine.update_stats(stats.data_ptr())
+    dev_scores = engine.fetch_scores(n)
+    res = engine.fetch(n)
+    st = stats.cpu().numpy()
+    scores, nq, pen, mild, dcnt = _expected_stats(pol, res)
+    assert st[0] == n and st[1] == 0 and st[2] == nq and nq > 0
+    np.testing.assert_allclose(dev_scores, scores, rtol=1e-14)
+    A = 26 * 61
+    np.testing.assert_allclose(st[8:8 + A].reshape(26, 61) / 2.0**32, pen, rtol=0, atol=n * 100 * 2.0**-31)
+    np.testing.assert_allclose(st[8 + A:8 + 2 * A].reshape(26, 61) / 2.0**32, mild, rtol=0, atol=n * 100 * 2.0**-31)
+    assert (st[8 + 2 * A:].reshape(26, 15) == dcnt).all()
+    assert (pen <= 0).all() and pen.min() < 0
+    # the statistics are integer sums: launching the same batch again gives the identical buffer
+    stats2 = torch.zeros_like(stats)
+    engine.launch(999, 0, n); engine.update_stats(stats2.data_ptr()); engine.sync()
+    assert torch.equal(stats, stats2)
+    # and they are shard-invariant: two half batches add up to the whole
+    parts = torch.zeros_like(stats)
+    for f in (0, n // 2):
+        t = torch.zeros_like(stats)
+        engine.launch(999, f, n // 2); engine.update_stats(t.data_ptr()); engine.sync()
+        parts += t
+    assert torch.equal(parts, stats)
+
+
+def test_reduced_update_moves_weights_the_right_way(engine):
+    pol = _seed_best(engine)
+    w0, dw0, _ = pol.tables()
+    n = 256
+    engine.upload_snapshot(pol); engine.launch(5, 0, n)
+    stats = torch.zeros(N.STATS_LEN, dtype=torch.int64, device="cuda")
+    engine.update_stats(stats.data_ptr())
+    scores = engine.fetch_scores(n)
+    b = int(np.argmax(scores))
+    improved = apply_reduced(pol, stats.cpu().numpy(), engine.fetch_episode_lists(b), noise_seed=3)
+    w1, dw1, _ = pol.tables()
+    assert pol.get("iteration_count") == 1 + n
+    assert w1.min() >= 1e-4 and w1.max() <= 0.999
+    st = stats.cpu().numpy(); A = 26 * 61
+    pen = st[8:8 + A].reshape(26, 61)
+    # actions that were only penalised went down; best actions (boosted, never penalised) went up
+    if st[2] > 0:
+        only_pen = (pen < 0)
+        best_occ = np.zeros((26, 61), bool)
+        # best lists before the update were those of config 1's episode
+        assert (w1[only_pen & ~best_occ] <= w0[only_pen & ~best_occ]).all() or improved
+    assert improved == (pol.get("iterations_without_improvement") == 0)
+
+
+def test_trainer_steps_are_deterministic(engine):
+    runs = []
+    for _ in range(2):
+        pol = ActionWeights()
+        tr = BatchTrainer(engine, pol, 128, 4321, replay_fraction=0.1)
+        flags = [tr.step() for _ in range(6)]
+        w, dw, _ = pol.tables()
+        runs.append((flags, w.tobytes(), dw.tobytes(), pol.get("iteration_count"), pol.lists(0)))
+    assert runs[0] == runs[1]
+    assert runs[0][0][0] is True and runs[0][3] == 6 * 128
