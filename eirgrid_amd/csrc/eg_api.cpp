@@ -216,7 +216,6 @@ int32_t eg_host_tables_i32(const eg_host_tables* h, const char* name, const int3
 int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o) {
   if (!c || !s || !s->weights || !s->deficit_weights) { set_error("eg_upload_snapshot: bad argument"); return EG_ERR_BAD_ARG; }
   if (o && o->enable_construction_delays) { set_error("enable_construction_delays is not implemented on the device (SURVEY §8(f) N4)"); return EG_ERR_UNSUPPORTED; }
-  if (s->iterations_without_improvement > 500u) { set_error("iterations_without_improvement > 500 (power-scaled sampling, sampling.rs:190-220) is not implemented on the device yet"); return EG_ERR_UNSUPPORTED; }
   EG_HIP(hipSetDevice(c->device));
   EG_HIP(hipMemcpy(c->d_w, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS, hipMemcpyHostToDevice));
   EG_HIP(hipMemcpy(c->d_dw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT, hipMemcpyHostToDevice));

@@ -20,6 +20,9 @@
 
 #include "eg_internal.h"
 
+#define EG_DETPOW_QUAL __device__ __forceinline__
+#include "eg_detpow.h"
+
 namespace eg {
 namespace {
 
@@ -42,7 +45,8 @@ struct __align__(16) Smem {
   uint16_t gcell[EG_MAX_GENS];        // cell | type << 12
   uint16_t opack[EG_MAX_OFFSETS];     // type | year << 4 | mult << 9
   uint8_t gbm[EG_MAX_GENS];           // build-year index | mult << 5
-  uint8_t ydef[256];                  // this year's deficit actions (success bonus, simulation.rs:505-519)
+  uint8_t ydef[256];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
+                                      // [128,192) sort permutation of the stalled sampler
 };
 static_assert(sizeof(Smem) <= 27306, "six episodes per CU need <= 160 KiB / 6 of LDS each");
 
@@ -270,6 +274,26 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Smem& sm, in
   double total = 0.0;
   for (int a = 0; a < EG_N_ACTIONS; ++a) total += sm.w[a];
   if (total <= 0.0) return 3 * kPeaker;
+  if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
+    const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
+    const double power = 1.0 + (2.0 * stagnation);
+    __syncthreads();
+    if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
+      const double mine = sm.w[lane];
+      int rank = 0;
+      for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
+      sm.fld[rank] = eg_detpow(mine, power);
+      sm.ydef[128 + rank] = (uint8_t)lane;
+    }
+    __syncthreads();
+    double total_scaled = 0.0;
+    for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.fld[i];
+    double v = rng_f64(r, sm, lane) * total_scaled;
+    int pick = sm.ydef[128];
+    for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.fld[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
+    __syncthreads();
+    return pick;
+  }
   double v = rng_f64(r, sm, lane) * total;
   for (int a = 0; a < EG_N_ACTIONS; ++a) { v -= sm.w[a]; if (v <= 0.0) return a; }
   return 3 * kPeaker;
@@ -404,7 +428,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
       ep.run_pos += 1; ep.n_run_y += 1;
     };
     auto push_def = [&](int action) {
-      if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 256) { ep.status = EG_EP_OVERFLOW; return; }
+      if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; return; }
       if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
       ep.def_pos += 1; ep.n_def_y += 1;
     };

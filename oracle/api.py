@@ -118,6 +118,10 @@ def lib():
     L.og_rng_stream.argtypes = [C.c_uint64, C.c_int32, u64p]
     L.og_rng_gen_range_probe.restype = C.c_uint64
     L.og_rng_gen_range_probe.argtypes = [C.c_uint64, C.c_uint64, C.c_int32]
+    L.og_detpow.restype = C.c_double
+    L.og_detpow.argtypes = [C.c_double, C.c_double]
+    L.og_libm_pow.restype = C.c_double
+    L.og_libm_pow.argtypes = [C.c_double, C.c_double]
     _lib = L
     return L
 

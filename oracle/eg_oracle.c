@@ -11,6 +11,7 @@
  * Citations are relative to /root/reference/aiSimulator/src/.
  */
 #include "eg_oracle.h"
+#include "../include/eg_detpow.h"   /* shared deterministic x^p, see the header */
 
 #include <math.h>
 #include <stdlib.h>
@@ -887,14 +888,15 @@ static int sample_action(og_weights *p, int yi) { /* sampling.rs:76-238 */
   if (should_explore) return (int)rng_range_u64(&p->rng, OG_NA);
   double total_weight = 0.0; for (int a = 0; a < OG_NA; ++a) total_weight += yw[a];
   if (total_weight <= 0.0) return 3 * T_PEAKER;
-  if (p->stall > 500) { /* power-scaled selection, stable sort by weight descending */
+  if (p->stall > 500) { /* power-scaled selection (sampling.rs:190-220), stable sort by weight descending; powf is
+                         * evaluated by the shared eg_detpow (include/eg_detpow.h), < 2e-14 relative from libm's pow */
     int order[OG_NA]; for (int a = 0; a < OG_NA; ++a) order[a] = a;
     for (int i = 1; i < OG_NA; ++i) { int k = order[i], j = i - 1; while (j >= 0 && yw[order[j]] < yw[k]) { order[j + 1] = order[j]; --j; } order[j + 1] = k; }
     double stagnation_factor = mind((double)p->stall / 1000.0, 3.0);
     double power_scaling = 1.0 + (2.0 * stagnation_factor);
-    double total_scaled = 0.0; for (int i = 0; i < OG_NA; ++i) total_scaled += pow(yw[order[i]], power_scaling);
+    double total_scaled = 0.0; for (int i = 0; i < OG_NA; ++i) total_scaled += eg_detpow(yw[order[i]], power_scaling);
     double random_val = rng_f64(&p->rng) * total_scaled;
-    for (int i = 0; i < OG_NA; ++i) { random_val -= pow(yw[order[i]], power_scaling); if (random_val <= 0.0) return order[i]; }
+    for (int i = 0; i < OG_NA; ++i) { random_val -= eg_detpow(yw[order[i]], power_scaling); if (random_val <= 0.0) return order[i]; }
     return order[0];
   }
   double random_val = rng_f64(&p->rng) * total_weight;
@@ -1486,3 +1488,6 @@ int32_t og_run_episode_tabled(const og_tables *T, og_weights *p, int32_t replay,
   free(m.gens); free(m.offs); free(m.fld);
   return out->status;
 }
+
+double og_detpow(double x, double p) { return eg_detpow(x, p); }
+double og_libm_pow(double x, double p) { return pow(x, p); }

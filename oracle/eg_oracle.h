@@ -148,6 +148,8 @@ void og_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, i
 void og_rng_seed_words(uint64_t seed, uint32_t key[8]);             /* rand_core seed_from_u64 */
 void og_rng_stream(uint64_t seed, int32_t n, uint64_t *out_u64);    /* first n next_u64() of StdRng::seed_from_u64 */
 uint64_t og_rng_gen_range_probe(uint64_t seed, uint64_t n, int32_t skip); /* gen_range(0..n) after `skip` u64 draws */
+double og_detpow(double x, double p);   /* include/eg_detpow.h as compiled into the oracle */
+double og_libm_pow(double x, double p);
 
 #ifdef __cplusplus
 }

@@ -82,3 +82,5 @@ def test_tables_stalled_and_best_state(world):
         w.set("best_net_emissions", -10.0); w.set("best_opinion", 0.7); w.set("best_cost", 9e11); w.set("best_reliability", 1.0)
     _check(world, [21, 22, 23], tweak=tweak)
     _check(world, [31, 32], tweak=lambda w: w.set_has_count_weights(0))
+    for stall in (600, 2500):      # power-scaled sampler
+        _check(world, [41, 42], tweak=lambda w, s=stall: w.set("stall", s))
