@@ -26,6 +26,18 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable)
 
 
+def host_cores() -> int:
+    """Threads this process may really use: the cgroup CPU quota if there is one, else the affinity mask (capped at 64)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(world, seconds_budget: float = 20.0):
     """The CPU oracle (C restatement of the reference algorithm — NOT the Rust/rayon binary, which cannot be built here)
     timed on this box's host cores: literal mode (same work as the reference: 100x100 candidate search with sqrt+div per
@@ -34,7 +46,7 @@ def cpu_baseline(world, seconds_budget: float = 20.0):
     from eirgrid_amd.engine import HostTables
     from oracle import api as O
     O.build()
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    cores = host_cores()
     ow = O.OracleWorld(world)
     t0 = time.perf_counter(); O.run_episode(ow, O.OracleWeights(), 1); one = time.perf_counter() - t0
     n_lit = max(cores, int(seconds_budget * 0.75 / max(one, 1e-3)))     # ≈ 15 s of CPU work
