@@ -15,7 +15,8 @@ STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
 
 EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeirgrid_hip.so")
+# EIRGRID_LIB selects another build of the same library (only used for the -DEG_STAMPS diagnostic build)
+LIB_PATH = os.environ.get("EIRGRID_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeirgrid_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)

@@ -159,7 +159,17 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   up(H.usage, &D.usage); up(H.population, &D.population);
   up(H.pre_co2, &D.pre_co2); up(H.pre_tg, &D.pre_tg); up(H.pre_ig, &D.pre_ig); up(H.pre_sg, &D.pre_sg);
   up(H.pre_optot, &D.pre_optot); up(H.pre_opcnt, &D.pre_opcnt);
-  up(H.te, &D.te); up(H.coastf, &D.coastf); up(H.dr, &D.dr);
+  {  // te is re-strided for the device so that each slice can be read 16 B per lane
+    std::vector<double> te_dev(size_t(kYears) * kRadiusClasses * kTeStride, 0.0);
+    for (int s = 0; s < kYears * kRadiusClasses; ++s)
+      std::memcpy(&te_dev[size_t(s) * kTeStride], &H.te[size_t(s) * kCells], sizeof(double) * kCells);
+    up(te_dev, &D.te);
+  }
+  {  // one pad element: the arg-max scan reads coastf 16 B at a time
+    std::vector<double> cf(H.coastf); cf.push_back(0.0); cf.push_back(0.0);
+    up(cf, &D.coastf);
+  }
+  up(H.dr, &D.dr);
   up(H.m03, &D.m03); up(H.t12, &D.t12); up(H.cc, &D.cc); up(H.out_mw, &D.out_mw); up(H.co2_t, &D.co2_t);
   up(H.cls, &D.cls); up(H.rclass, &D.rclass); up(H.marine, &D.marine); up(H.reach, &D.reach);
   up(H.offv, &D.offv); up(H.offc, &D.offc); up(H.inflation, &D.inflation); up(H.carbon_price, &D.carbon_price);

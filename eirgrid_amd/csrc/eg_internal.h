@@ -16,6 +16,7 @@ constexpr int kRadiusClasses = 6;
 constexpr int kMaxReach = 12;   // cells; the largest penalty radius is 12 km
 constexpr int kMults = 3;
 constexpr int kOffsetTypes = 4;
+constexpr int kTeStride = 2608;   // device copy of te: every [year][class] slice starts 64 B aligned (2601 -> 2608 doubles)
 
 // Policy-independent tables, built once per world on the host (eg_tables.cpp) and mirrored in HBM.
 // Everything a kernel needs that involves sqrt / division by data / pow / exp lives here, so device code only

@@ -38,23 +38,27 @@ __constant__ int c_deficit_type[14] = {8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13
 __constant__ int c_deficit_slot[15] = {5, 6, 10, 11, 7, 9, -1, 1, 0, 4, 8, 3, 2, 12, 13};
 
 struct __align__(16) Smem {
-  double fld[kCells];                 // placement score field of the current search
+  double fld[kCells + 1];             // placement score field of the current search (+1: filled 16 B at a time)
   double w[64];                       // this year's main weights (61 used)
   double dw[16];                      // this year's deficit weights (15 used)
+  double cw[24];                      // this year's action-count weights (21 used)
   uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
+  uint32_t rng_key[8];                // ChaCha12 key of the episode stream
+  unsigned long long rng_counter;     // next block counter
   uint16_t gcell[EG_MAX_GENS];        // cell | type << 12
   uint16_t opack[EG_MAX_OFFSETS];     // type | year << 4 | mult << 9
   uint8_t gbm[EG_MAX_GENS];           // build-year index | mult << 5
-  uint8_t ydef[256];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
+  uint8_t ydef[192];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
                                       // [128,192) sort permutation of the stalled sampler
 };
 static_assert(sizeof(Smem) <= 27306, "six episodes per CU need <= 160 KiB / 6 of LDS each");
 
-struct Rng {
-  uint32_t key[8];
-  unsigned long long counter;
+// One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
+__shared__ Smem sm;
+
+struct Rng {      // register part of the stream state; key / counter / buffer live in LDS
   int index;
-  unsigned long long words;
+  unsigned int words;
 };
 
 struct Agg {   // aggregates of the map at the current point of the year (map_handler.rs:819-965)
@@ -72,79 +76,84 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return (v << n) 
   a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12);           \
   a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
 
-__device__ void chacha12_block(const uint32_t* key, unsigned long long counter, uint32_t* out) {
-  uint32_t s[16], x[16];
-  s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+// Four consecutive ChaCha12 blocks (rand_chacha fills 64 words per refill), one per lane 0..3.  Not inlined: the
+// episode code draws from ~10 places and the block function is ~1.2k instructions.
+__device__ __noinline__ void rng_refill(int lane) {
+  __syncthreads();
+  if (lane < 4) {
+    const unsigned long long counter = sm.rng_counter + (unsigned long long)lane;
+    uint32_t s[16], x[16];
+    s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s[4 + i] = key[i];
-  s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0u; s[15] = 0u;
+    for (int i = 0; i < 8; ++i) s[4 + i] = sm.rng_key[i];
+    s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0u; s[15] = 0u;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) x[i] = s[i];
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
 #pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
-    EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+    for (int r = 0; r < 6; ++r) {
+      EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
+      EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sm.rng[16 * lane + i] = x[i] + s[i];
   }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+  __syncthreads();
+  if (lane == 0) sm.rng_counter += 4ull;
+  __syncthreads();
 }
 
-__device__ void rng_seed(Rng& r, unsigned long long state) {   // rand_core 0.6.4 seed_from_u64
+__device__ void rng_seed(Rng& r, unsigned long long state, int lane) {   // rand_core 0.6.4 seed_from_u64
   const unsigned long long MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     state = state * MUL + INC;
     uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
     uint32_t rot = (uint32_t)(state >> 59);
-    r.key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    if (lane == 0) sm.rng_key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
   }
-  r.counter = 0; r.index = 64; r.words = 0;
-}
-__device__ void rng_refill(Rng& r, Smem& sm, int lane) {   // four consecutive blocks, one per lane 0..3
+  if (lane == 0) sm.rng_counter = 0ull;
   __syncthreads();
-  if (lane < 4) chacha12_block(r.key, r.counter + (unsigned long long)lane, &sm.rng[16 * lane]);
-  r.counter += 4;
-  __syncthreads();
+  r.index = 64; r.words = 0;
 }
-__device__ unsigned long long rng_u64(Rng& r, Smem& sm, int lane) {   // BlockRng::next_u64
+__device__ __forceinline__ unsigned long long rng_u64(Rng& r, int lane) {   // BlockRng::next_u64
   r.words += 1;
-  if (r.index < 63) {
-    unsigned long long v = ((unsigned long long)sm.rng[r.index + 1] << 32) | sm.rng[r.index];
-    r.index += 2;
-    return v;
+  unsigned long long lo;
+  if (r.index >= 63) {                      // one word left (63) or none (>= 64): refill once
+    const bool straddle = r.index == 63;
+    const uint32_t tail = sm.rng[63];
+    rng_refill(lane);
+    if (straddle) { r.index = 1; return ((unsigned long long)sm.rng[0] << 32) | tail; }
+    r.index = 0;
   }
-  if (r.index >= 64) {
-    rng_refill(r, sm, lane); r.index = 2;
-    return ((unsigned long long)sm.rng[1] << 32) | sm.rng[0];
-  }
-  unsigned long long x = sm.rng[63];
-  rng_refill(r, sm, lane); r.index = 1;
-  return ((unsigned long long)sm.rng[0] << 32) | x;
+  lo = sm.rng[r.index];
+  const unsigned long long hi = sm.rng[r.index + 1];
+  r.index += 2;
+  return (hi << 32) | lo;
 }
-__device__ uint32_t rng_u32(Rng& r, Smem& sm, int lane) {   // BlockRng::next_u32
+__device__ __forceinline__ uint32_t rng_u32(Rng& r, int lane) {   // BlockRng::next_u32
   r.words += 1;
-  if (r.index >= 64) { rng_refill(r, sm, lane); r.index = 0; }
-  uint32_t v = sm.rng[r.index];
+  if (r.index >= 64) { rng_refill(lane); r.index = 0; }
+  const uint32_t v = sm.rng[r.index];
   r.index += 1;
   return v;
 }
-__device__ double rng_f64(Rng& r, Smem& sm, int lane) {   // Standard: 53 bits, [0,1)
-  return (double)(rng_u64(r, sm, lane) >> 11) * (1.0 / 9007199254740992.0);
+__device__ __forceinline__ double rng_f64(Rng& r, int lane) {   // Standard: 53 bits, [0,1)
+  return (double)(rng_u64(r, lane) >> 11) * (1.0 / 9007199254740992.0);
 }
-__device__ unsigned long long rng_range64(Rng& r, Smem& sm, int lane, unsigned long long range) {
-  unsigned long long zone = (range << __clzll((long long)range)) - 1ull;   // uniform.rs sample_single_inclusive
+__device__ unsigned long long rng_range64(Rng& r, int lane, unsigned long long range) {
+  const unsigned long long zone = (range << __clzll((long long)range)) - 1ull;   // uniform.rs sample_single_inclusive
   for (int guard = 0; guard < 4096; ++guard) {
-    unsigned long long v = rng_u64(r, sm, lane);
-    unsigned long long hi = __umul64hi(v, range), lo = v * range;
+    const unsigned long long v = rng_u64(r, lane);
+    const unsigned long long hi = __umul64hi(v, range), lo = v * range;
     if (lo <= zone) return hi;
   }
   return 0;
 }
-__device__ uint32_t rng_range32(Rng& r, Smem& sm, int lane, uint32_t range) {
-  uint32_t zone = (range << __clz((int)range)) - 1u;
+__device__ uint32_t rng_range32(Rng& r, int lane, uint32_t range) {
+  const uint32_t zone = (range << __clz((int)range)) - 1u;
   for (int guard = 0; guard < 4096; ++guard) {
-    uint32_t v = rng_u32(r, sm, lane);
-    unsigned long long m = (unsigned long long)v * range;
+    const uint32_t v = rng_u32(r, lane);
+    const unsigned long long m = (unsigned long long)v * range;
     if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
   }
   return 0;
@@ -172,50 +181,108 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 // fld[c] starts from te[year][class][c] (settlement product, then existing plant, in list order), is multiplied by
 // d/R for every generator added so far in list order, then by the coast factor (marine types) and the size
 // factor.  Strict '>' against a running best that starts at 0.0, candidates in (i, j) order: first maximum wins.
-__device__ int place_search(const DevTables& T, Smem& sm, int lane, int yi, int type, int ngen, double* best_score) {
-  const int rc = T.rclass[type];
-  const double* te = T.te + ((size_t)yi * kRadiusClasses + rc) * kCells;
-  for (int c = lane; c < kCells; c += kWave) sm.fld[c] = te[c];
-  __syncthreads();
-  const int reach = T.reach[rc];
+//
+// Lane l owns box position l + 64*p of the (2*reach+1)^2 penalty box in pass p; its offset (di, dj) and factor d/R do
+// not depend on the generator, so they sit in registers for the whole search and the generator loop is one LDS
+// read-modify-write per pass.  A wave's LDS operations execute in program order, so consecutive generators need no
+// barrier between them even when their boxes overlap.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+template <int NPASS>
+__device__ __forceinline__ void apply_generator_penalties(int lane, int reach, const double* __restrict__ dr, int ngen) {
   const int side = 2 * reach + 1, box = side * side;
-  const double* dr = T.dr + (size_t)rc * 169;
+  double f[NPASS]; int off[NPASS];   // off: di | dj << 8 (biased by 16), or -1 when the lane has no box cell in this pass
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+    const int idx = lane + kWave * p;
+    const int bi = idx / side, bj = idx - bi * side;
+    const int di = bi - reach, dj = bj - reach;
+    const bool valid = idx < box;
+    const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+    f[p] = valid ? dr[adi * 13 + adj] : 1.0;
+    off[p] = valid ? ((di + 16) | ((dj + 16) << 8)) : -1;
+  }
   for (int g = 0; g < ngen; ++g) {
     const int gc = sm.gcell[g] & 0xFFF;
     const int gi = gc / kGrid, gj = gc - gi * kGrid;
-    for (int idx = lane; idx < box; idx += kWave) {
-      const int bi = idx / side, bj = idx - bi * side;
-      const int di = bi - reach, dj = bj - reach;
-      const int ci = gi + di, cj = gj + dj;
-      if (ci >= 0 && ci < kGrid && cj >= 0 && cj < kGrid) {
-        const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int ci = gi + (off[p] & 0xFF) - 16, cj = gj + ((off[p] >> 8) & 0xFF) - 16;
+      if (off[p] >= 0 && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {
         const int c = ci * kGrid + cj;
-        sm.fld[c] = sm.fld[c] * dr[adi * 13 + adj];
+        sm.fld[c] = sm.fld[c] * f[p];
       }
     }
+  }
+}
+
+__device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score) {
+  const int rc = T.rclass[type];
+  {   // field <- te[yi][rc][:], 16 B per lane per load, all 21 loads in flight before the first LDS store
+    const double2* te2 = reinterpret_cast<const double2*>(T.te + ((size_t)yi * kRadiusClasses + rc) * kTeStride);
+    double2* f2 = reinterpret_cast<double2*>(sm.fld);
     __syncthreads();
-  }
-  const bool marine = T.marine[type] != 0;
-  double best = 0.0; int best_c = kCells;
-  for (int c = lane; c < kCells; c += kWave) {
-    double s = sm.fld[c];
-    if (marine) s = s * T.coastf[c];
-    s = s * T.size_factor;
-    if (s > best) { best = s; best_c = c; }
-  }
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    double ob = __shfl_xor(best, off);
-    int oc = __shfl_xor(best_c, off);
-    if (ob > best || (ob == best && oc < best_c)) { best = ob; best_c = oc; }
+    for (int h = 0; h < 3; ++h) {       // three groups of seven loads in flight
+      double2 v[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { const int i = lane + kWave * (7 * h + k); v[k] = i < (kCells + 1) / 2 ? te2[i] : make_double2(0.0, 0.0); }
+#pragma unroll
+      for (int k = 0; k < 7; ++k) { const int i = lane + kWave * (7 * h + k); if (i < (kCells + 1) / 2) f2[i] = v[k]; }
+    }
   }
   __syncthreads();
-  if (best_score) *best_score = best;
-  return best > 0.0 ? best_c : -1;
+  const int reach = T.reach[rc];
+  const double* dr = T.dr + (size_t)rc * 169;
+  if (ngen > 0) {
+    switch (reach) {   // passes = ceil((2*reach+1)^2 / 64)
+      case 2: apply_generator_penalties<1>(lane, reach, dr, ngen); break;    // 3 km:  25 cells
+      case 4: apply_generator_penalties<2>(lane, reach, dr, ngen); break;    // 5 km:  81
+      case 5: apply_generator_penalties<2>(lane, reach, dr, ngen); break;    // 6 km: 121
+      case 6: apply_generator_penalties<3>(lane, reach, dr, ngen); break;    // 7 km: 169
+      case 7: apply_generator_penalties<4>(lane, reach, dr, ngen); break;    // 8 km: 225
+      default: apply_generator_penalties<9>(lane, reach, dr, ngen); break;   // 12 km: 529
+    }
+  }
+  __syncthreads();
+  const bool marine = T.marine[type] != 0;
+  double best = 0.0; int best_c = kCells;
+  {   // lane l scans cells 2i, 2i+1 for i = l + 64k: ascending within the lane, so a strict '>' keeps the first maximum
+    const double2* f2 = reinterpret_cast<const double2*>(sm.fld);
+    const double2* cf2 = reinterpret_cast<const double2*>(T.coastf);
+#pragma unroll 7
+    for (int k = 0; k < 21; ++k) {
+      const int i = lane + kWave * k;
+      if (i < (kCells + 1) / 2) {
+        double2 sv = f2[i];
+        if (marine) { const double2 cf = cf2[i]; sv.x = sv.x * cf.x; sv.y = sv.y * cf.y; }
+        sv.x = sv.x * T.size_factor; sv.y = sv.y * T.size_factor;
+        if (sv.x > best) { best = sv.x; best_c = 2 * i; }
+        if (2 * i + 1 < kCells && sv.y > best) { best = sv.y; best_c = 2 * i + 1; }
+      }
+    }
+  }
+  double wmax = best;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const double other = __shfl_xor(wmax, o); wmax = other > wmax ? other : wmax; }
+  const unsigned long long holders = __ballot(best == wmax);
+  int win_c;
+  if (__popcll(holders) == 1) {
+    win_c = __builtin_amdgcn_readlane(best_c, __ffsll((long long)holders) - 1);
+  } else {                        // equal maxima in several lanes: the lowest cell index is the first in (i, j) order
+    win_c = best == wmax ? best_c : kCells;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(win_c, o); win_c = other < win_c ? other : win_c; }
+  }
+  __syncthreads();
+  if (best_score) *best_score = wmax;
+  return wmax > 0.0 ? win_c : -1;
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
-__device__ void update_weights(const DevSnapshot& S, Smem& sm, int lane, int action, double improvement) {
+__device__ void update_weights(const DevSnapshot& S, int lane, int action, double improvement) {
   // learning.rs:21-88; rel_improvement / immediate_weight are the host-evaluated :37-54
   const double combined = S.immediate_weight * improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
   const double adj = combined > 0.0 ? 1.0 + (S.learning_rate * combined)
@@ -231,7 +298,7 @@ __device__ void update_weights(const DevSnapshot& S, Smem& sm, int lane, int act
     __syncthreads();
   }
 }
-__device__ void update_deficit_weights(const DevSnapshot& S, Smem& sm, int lane, int action, double improvement) {
+__device__ void update_deficit_weights(const DevSnapshot& S, int lane, int action, double improvement) {
   // deficit.rs:82-135; every action that reaches here is AddGenerator(type, 100 %)
   int slot = -1;
   if (action < kFirstOffset && (action % 3) == 0) slot = c_deficit_slot[action / 3];
@@ -250,28 +317,35 @@ __device__ void update_deficit_weights(const DevSnapshot& S, Smem& sm, int lane,
 }
 
 // ---- sampling (canonical table order; see include/eirgrid_hip.h) -------------------------------------------
-__device__ int smart_fallback(Rng& r, Smem& sm, int lane, int year) {   // sampling.rs:445-490
+__device__ int smart_fallback(Rng& r, int lane, int year) {   // sampling.rs:445-490
   const uint32_t offw = year < 2035 ? 5u : (year < 2045 ? 15u : 25u);
-  const int acts[7] = {0, 3, 12, 3 * kBattery, kFirstOffset, kFirstOffset + 6, 21};
-  const uint32_t wts[7] = {15u, 10u, 15u, year < 2035 ? 10u : 20u, offw, offw, year < 2035 ? 15u : (year < 2045 ? 10u : 5u)};
-  uint32_t total = 0;
-  for (int i = 0; i < 7; ++i) total += wts[i];
-  uint32_t choice = rng_range32(r, sm, lane, total);
-  for (int i = 0; i < 7; ++i) { if (choice < wts[i]) return acts[i]; choice -= wts[i]; }
+  const uint32_t w3 = year < 2035 ? 10u : 20u, w6 = year < 2035 ? 15u : (year < 2045 ? 10u : 5u);
+  const uint32_t total = 15u + 10u + 15u + w3 + offw + offw + w6;
+  uint32_t choice = rng_range32(r, lane, total);
+  if (choice < 15u) return 0;              choice -= 15u;     // OnshoreWind
+  if (choice < 10u) return 3;              choice -= 10u;     // OffshoreWind
+  if (choice < 15u) return 12;             choice -= 15u;     // UtilitySolar
+  if (choice < w3) return 3 * kBattery;    choice -= w3;
+  if (choice < offw) return kFirstOffset;  choice -= offw;    // Forest
+  if (choice < offw) return kFirstOffset + 6; choice -= offw; // ActiveCapture
+  if (choice < w6) return 21;                                  // GasCombinedCycle
   return 3 * kBattery;
 }
-__device__ int smart_deficit_fallback(Rng& r, Smem& sm, int lane) {   // sampling.rs:492-528
-  const int acts[6] = {3 * kPeaker, 3 * kBattery, 21, 0, 3, 12};
-  const uint32_t wts[6] = {30u, 30u, 20u, 10u, 0u, 3u};
-  uint32_t choice = rng_range32(r, sm, lane, 93u);
-  for (int i = 0; i < 6; ++i) { if (choice < wts[i]) return acts[i]; choice -= wts[i]; }
+__device__ int smart_deficit_fallback(Rng& r, int lane) {   // sampling.rs:492-528: weights 30, 30, 20, 10, 0, 3
+  uint32_t choice = rng_range32(r, lane, 93u);
+  if (choice < 30u) return 3 * kPeaker;   choice -= 30u;
+  if (choice < 30u) return 3 * kBattery;  choice -= 30u;
+  if (choice < 20u) return 21;            choice -= 20u;
+  if (choice < 10u) return 0;             choice -= 10u;
+  if (choice < 3u) return 12;
   return 3 * kBattery;
 }
-__device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Smem& sm, int lane) {   // sampling.rs:147-237
+__device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, int lane) {   // sampling.rs:147-237
   const double eps = S.stall > 100u ? S.exploration_rate * (1.0 / (1.0 + 0.01 * (double)S.stall)) : S.exploration_rate;
-  const bool explore = rng_f64(r, sm, lane) < eps;
-  if (explore) return (int)rng_range64(r, sm, lane, (unsigned long long)EG_N_ACTIONS);
+  const bool explore = rng_f64(r, lane) < eps;
+  if (explore) return (int)rng_range64(r, lane, (unsigned long long)EG_N_ACTIONS);
   double total = 0.0;
+#pragma unroll 4
   for (int a = 0; a < EG_N_ACTIONS; ++a) total += sm.w[a];
   if (total <= 0.0) return 3 * kPeaker;
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
@@ -281,30 +355,36 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Smem& sm, in
     if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
       const double mine = sm.w[lane];
       int rank = 0;
+#pragma unroll 4
       for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
       sm.fld[rank] = eg_detpow(mine, power);
       sm.ydef[128 + rank] = (uint8_t)lane;
     }
     __syncthreads();
     double total_scaled = 0.0;
+#pragma unroll 4
     for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.fld[i];
-    double v = rng_f64(r, sm, lane) * total_scaled;
+    double v = rng_f64(r, lane) * total_scaled;
     int pick = sm.ydef[128];
+#pragma unroll 4
     for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.fld[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
     __syncthreads();
     return pick;
   }
-  double v = rng_f64(r, sm, lane) * total;
+  double v = rng_f64(r, lane) * total;
+#pragma unroll 4
   for (int a = 0; a < EG_N_ACTIONS; ++a) { v -= sm.w[a]; if (v <= 0.0) return a; }
   return 3 * kPeaker;
 }
-__device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Smem& sm, int lane) {   // sampling.rs:315-377
-  const bool explore = rng_f64(r, sm, lane) < S.exploration_rate;
-  if (explore) return 3 * c_deficit_type[(int)rng_range64(r, sm, lane, 14ull)];
+__device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, int lane) {   // sampling.rs:315-377
+  const bool explore = rng_f64(r, lane) < S.exploration_rate;
+  if (explore) return 3 * c_deficit_type[(int)rng_range64(r, lane, 14ull)];
   double total = 0.0;
+#pragma unroll 2
   for (int i = 0; i < 14; ++i) total += sm.dw[i];
   if (total <= 0.0) return 3 * kPeaker;
-  double v = rng_f64(r, sm, lane) * total;
+  double v = rng_f64(r, lane) * total;
+#pragma unroll 2
   for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; if (v <= 0.0) return 3 * c_deficit_type[i]; }
   return 3 * kPeaker;
 }
@@ -317,18 +397,29 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   double bytes;
 };
 
+#ifdef EG_STAMPS
+#define EG_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
+#define EG_T1(slot) stamps[slot] += __builtin_readcyclecounter() - t0_
+#else
+#define EG_T0() do {} while (0)
+#define EG_T1(slot) do {} while (0)
+#endif
+
 __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
                                                    unsigned long long first_index, uint32_t n_episodes,
                                                    const uint8_t* __restrict__ replay_mask) {
-  __shared__ Smem sm;
   const int lane = threadIdx.x;
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
   const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
   const int n_existing = T.n_existing;
+#ifdef EG_STAMPS
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
 
   Rng rng;
-  rng_seed(rng, seed + first_index + (unsigned long long)e);   // simulation.rs:50-53, one stream per episode
+  rng_seed(rng, seed + first_index + (unsigned long long)e, lane);   // simulation.rs:50-53, one stream per episode
 
   Episode ep;
   ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32.0;
@@ -340,6 +431,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
   uint16_t* off_pack = O.off_pack + (size_t)e * EG_MAX_OFFSETS;
 
   double gcost_end = 0.0, ocost_end = 0.0;                 // last year's end-of-year capital sums
+  double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
   double total_cost = 0.0, total_credit = 0.0, total_sales = 0.0;   // accumulators of metrics_calculation.rs:133-153
   double last_net = 0.0, last_opinion = 0.0, last_capital = 0.0, last_balance = 0.0;
 
@@ -349,49 +441,159 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     __syncthreads();
     if (lane < EG_N_ACTIONS) sm.w[lane] = S.w[yi * EG_N_ACTIONS + lane];
     if (lane < EG_N_DEFICIT) sm.dw[lane] = S.dw[yi * EG_N_DEFICIT + lane];
+    if (S.cw != nullptr && lane < EG_N_COUNTS) sm.cw[lane] = S.cw[yi * EG_N_COUNTS + lane];
     __syncthreads();
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
 
-    // ---- aggregates at the start of the year: existing plant first, then every generator in list order ----
+    // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
+    //      The lanes gather the per-generator terms in parallel; the sums are then folded lane by lane (readlane),
+    //      i.e. in list order.  Output / CO2 terms of a plant never change (delays off), so those three sums carry
+    //      over from the end of last year whenever the existing-plant prefix did, bit for bit. ----
     Agg a;
-    a.co2 = T.pre_co2[yi]; a.tg = T.pre_tg[yi]; a.ig = T.pre_ig[yi]; a.sg = T.pre_sg[yi];
-    a.optot = T.pre_optot[yi]; a.opcnt = T.pre_opcnt[yi]; a.usage = T.usage[yi];
+    a.usage = T.usage[yi];
     a.gcost = 0.0; a.ocost = 0.0; a.offs = 0.0;
     a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
+    a.optot = T.pre_optot[yi]; a.opcnt = T.pre_opcnt[yi];
     {
+      EG_T0();
+      const double pco2 = T.pre_co2[yi], ptg = T.pre_tg[yi], pig = T.pre_ig[yi], psg = T.pre_sg[yi];
+      const bool carry = yi > 0 && pco2 == T.pre_co2[yi - 1] && ptg == T.pre_tg[yi - 1] && pig == T.pre_ig[yi - 1] && psg == T.pre_sg[yi - 1];
+      if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
+      else { a.co2 = pco2; a.tg = ptg; a.ig = pig; a.sg = psg; }
       const double* ccy = T.cc + (size_t)yi * kTypes * kYears * kMults * 2;
       const double* t12y = T.t12 + (size_t)yi * kTypes;
-      for (int g = 0; g < ep.ngen; ++g) {
-        const int gc = sm.gcell[g], bm = sm.gbm[g];
+      const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
+      for (int base = 0; base < ngen_s; base += kWave) {
+        const int g = base + lane;
+        const bool valid = g < ngen_s;
+        const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
         const int cell = gc & 0xFFF, t = gc >> 12, b = bm & 31, m = bm >> 5;
-        const double* cc = ccy + ((size_t)(t * kYears + b) * kMults + m) * 2;
-        a.gcost += cc[0];
-        a.co2 += T.co2_t[t];
-        const double out = T.out_mw[t];
-        const int cls = T.cls[t];
-        if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
-        a.optot += (T.m03[cell] + t12y[t]) + cc[1];
-        a.opcnt += 1;
+        const double2 cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t * kYears + b) * kMults + m) * 2);
+        const double op = (T.m03[cell] + t12y[t]) + cc.y;
+        double out = 0.0, co2 = 0.0; int cls = 0;
+        if (!carry) { out = T.out_mw[t]; co2 = T.co2_t[t]; cls = T.cls[t]; }
+        const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
+        for (int j = 0; j < cnt; ++j) {
+          a.gcost += readlane_f64(cc.x, j);
+          a.optot += readlane_f64(op, j);
+          if (!carry) {
+            const double oj = readlane_f64(out, j);
+            const int cj = __builtin_amdgcn_readlane(cls, j);
+            a.co2 += readlane_f64(co2, j);
+            if (cj == 1) a.ig += oj; else if (cj == 2) a.sg += oj; else a.tg += oj;
+          }
+        }
+        a.opcnt += cnt;
       }
       const double* offvy = T.offv + (size_t)yi * kOffsetTypes * kYears;
       const double* offcy = T.offc + (size_t)yi * kOffsetTypes * kMults;
-      for (int k = 0; k < ep.noff; ++k) {
-        const int p = sm.opack[k];
+      const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
+      for (int base = 0; base < noff_s; base += kWave) {
+        const int k = base + lane;
+        const int p = k < noff_s ? sm.opack[k] : 0;
         const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
-        a.offs += offvy[ot * kYears + b];
-        a.ocost += offcy[ot * kMults + m];
+        const double ov = offvy[ot * kYears + b], oc = offcy[ot * kMults + m];
+        const int cnt = noff_s - base < kWave ? noff_s - base : kWave;
+        for (int j = 0; j < cnt; ++j) { a.offs += readlane_f64(ov, j); a.ocost += readlane_f64(oc, j); }
       }
+      EG_T1(0);
     }
     ep.bytes += 2.0 * (double)(n_existing + ep.ngen) * 56.0 + 2.0 * (double)ep.noff * 8.0 + 184.0;
 
-    // apply one action to the map (actions.rs:40-204) and fold it into the aggregates
-    auto apply = [&](int action) {
+    // ---- the year's actions: phase 0 = deficit repair (simulation.rs:137-141, :319-522),
+    //      phase 1 = additional actions (simulation.rs:144-198).  One loop so that apply_action is emitted once. ----
+    int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
+    const State year_start = state_of(a);
+    int phase = year_start.balance < 0.0 ? 0 : 1;
+    const State initial = year_start;
+    double remaining = -year_start.balance;
+    uint32_t attempts = 0, n_add = 0, k_add = 0;
+    bool n_add_known = false;
+    State cur = year_start;
+
+    for (int guard = 0; guard < 200000 && ep.status == EG_EP_OK; ++guard) {
+      int action;
+      if (phase == 0) {
+        if (!(remaining > 0.0)) {   // deficit closed: success bonus (simulation.rs:491-519), then go on to phase 1
+          const State fin = state_of(a);
+          const double success = evaluate_impact(initial, fin);
+          if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
+            const double factor = 0.1 * success;
+            __syncthreads();
+            for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, lane, sm.ydef[i], factor);
+          }
+          phase = 1;
+          continue;
+        }
+        attempts += 1;
+        EG_T0();
+        if (attempts < 5u) {
+          if (replay) {   // sampling.rs:242-313
+            const int lo = S.bestd_off[yi], n = S.bestd_off[yi + 1] - lo;
+            if (S.has_best_deficit && replay_def_idx < n) { action = S.bestd_actions[lo + replay_def_idx]; replay_def_idx += 1; }
+            else action = smart_deficit_fallback(rng, lane);
+            if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; break; }
+            if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
+            ep.def_pos += 1; ep.n_def_y += 1;
+          } else action = sample_deficit_weighted(S, rng, lane);
+        } else action = 3 * kBattery;   // simulation.rs:369-376
+        EG_T1(2);
+        if (action >= kFirstOffset) continue;   // only AddGenerator actions are applied in the repair loop (:398)
+        cur = state_of(a);
+      } else {
+        if (!n_add_known) {   // simulation.rs:144-187
+          n_add_known = true;
+          EG_T0();
+          if (replay) {
+            n_add = S.has_best_actions ? (uint32_t)(S.best_off[yi + 1] - S.best_off[yi]) : 0u;
+          } else {   // sampling.rs:380-443
+            const uint32_t dcount = (uint32_t)ep.n_def_y;
+            const uint32_t cap = dcount >= 20u ? 0u : 20u - dcount;
+            if (cap > 0u) {
+              const double u = rng_f64(rng, lane);
+              if (S.cw != nullptr) {
+                const double* cw = sm.cw;
+                double total = 0.0;
+#pragma unroll 3
+                for (int c = 0; c < EG_N_COUNTS; ++c) total += cw[c];
+                if (total > 0.0) {
+                  double v = u * total;
+                  n_add = 5u < cap ? 5u : cap;
+#pragma unroll 3
+                  for (uint32_t c = 0; c < (uint32_t)EG_N_COUNTS; ++c) { v -= cw[c]; if (v <= 0.0) { n_add = c < cap ? c : cap; break; } }
+                }
+              } else {   // heuristic branch; min/max actions were evaluated on the host (sampling.rs:425-427)
+                const uint32_t hi = S.heur_max < cap ? S.heur_max : cap;
+                const uint32_t lo = S.heur_min < hi ? S.heur_min : hi;
+                n_add = lo == hi ? lo : lo + rng_range32(rng, lane, hi - lo + 1u);
+              }
+            }
+          }
+          EG_T1(2);
+        }
+        if (k_add >= n_add) break;
+        k_add += 1;
+        EG_T0();
+        if (replay) {   // sampling.rs:78-145
+          const int lo = S.best_off[yi], n = S.best_off[yi + 1] - lo;
+          if (S.has_best_actions && replay_idx < n) { action = S.best_actions[lo + replay_idx]; replay_idx += 1; }
+          else action = smart_fallback(rng, lane, year);
+          if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
+          if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
+          ep.run_pos += 1; ep.n_run_y += 1;
+        } else action = sample_action_weighted(S, rng, lane);
+        EG_T1(2);
+      }
+
+      // ---- apply_action (actions.rs:40-204), folded into the aggregates ----
       if (action < kFirstOffset) {
         const int t = action / 3, m = action - 3 * t;
         ep.bytes += (double)kCells * 8.0 + (double)(n_existing + ep.ngen) * 16.0;
-        const int cell = place_search(T, sm, lane, yi, t, ep.ngen, nullptr);
-        if (cell < 0) { ep.status = EG_EP_NO_LOCATION; return; }   // actions.rs:77-89 is unreachable here (Q16)
-        if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; return; }
+        EG_T0();
+        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr);
+        EG_T1(1);
+        if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
+        if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) {
           sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
           sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
@@ -411,7 +613,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         a.opcnt += 1;
       } else if (action < kFirstOther) {
         const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
-        if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; return; }
+        if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; break; }
         const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9));
         if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
         __syncthreads();
@@ -421,115 +623,34 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         if (yi > 0) a.ocost_prev += T.offc[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
       }
       // 57..59 carry an empty generator id (core.rs:117-119): the lookup fails, nothing changes.  60: DoNothing.
-    };
-    auto push_run = [&](int action) {
-      if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; return; }
-      if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
-      ep.run_pos += 1; ep.n_run_y += 1;
-    };
-    auto push_def = [&](int action) {
-      if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; return; }
-      if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
-      ep.def_pos += 1; ep.n_def_y += 1;
-    };
 
-    int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
-
-    // ---- deficit repair (simulation.rs:137-141, :319-522) ----
-    const State year_start = state_of(a);
-    if (year_start.balance < 0.0) {
-      const State initial = year_start;
-      double remaining = -year_start.balance;
-      uint32_t attempts = 0;
-      while (remaining > 0.0 && ep.status == EG_EP_OK) {
-        attempts += 1;
-        int action;
-        if (attempts < 5u) {
-          if (replay) {   // sampling.rs:242-313
-            if (S.has_best_deficit) {
-              const int lo = S.bestd_off[yi], n = S.bestd_off[yi + 1] - lo;
-              if (replay_def_idx < n) { action = S.bestd_actions[lo + replay_def_idx]; replay_def_idx += 1; }
-              else action = smart_deficit_fallback(rng, sm, lane);
-            } else action = smart_deficit_fallback(rng, sm, lane);
-            push_def(action);
-          } else action = sample_deficit_weighted(S, rng, sm, lane);
-        } else action = 3 * kBattery;   // simulation.rs:369-376
-        if (attempts > 100000u) { ep.status = EG_EP_OVERFLOW; break; }
-        if (action < kFirstOffset) {
-          const State cur = state_of(a);
-          apply(action);
-          if (ep.status != EG_EP_OK) break;
-          push_def(action); push_run(action);   // simulation.rs:406-409
-          const State nxt = state_of(a);
-          const double overall = evaluate_impact(cur, nxt);
-          const double em = nxt.net < cur.net ? (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0) : 0.0;
-          double ci = 0.0;
-          if (nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; ci = -cost_change / dmax(dabs(cur.cost), 1.0); }
-          const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
-          const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
-          update_deficit_weights(S, sm, lane, action, combined);
-          update_weights(S, sm, lane, action, overall * 0.5);
-          remaining = -dmin(nxt.balance, 0.0);
-        }
+      if (phase == 0) {   // simulation.rs:406-486
+        if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128 || ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
+        if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; run_log[ep.run_pos] = (uint8_t)action; }
+        ep.def_pos += 1; ep.n_def_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
+        EG_T0();
+        const State nxt = state_of(a);
+        const double overall = evaluate_impact(cur, nxt);
+        const double em = nxt.net < cur.net ? (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0) : 0.0;
+        double ci = 0.0;
+        if (nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; ci = -cost_change / dmax(dabs(cur.cost), 1.0); }
+        const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
+        const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
+        update_deficit_weights(S, lane, action, combined);
+        update_weights(S, lane, action, overall * 0.5);
+        remaining = -dmin(nxt.balance, 0.0);
+        EG_T1(3);
+      } else {            // simulation.rs:193-197
+        if (ep.act_pos >= EG_ACT_CAP || ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
+        if (lane == 0) { act_log[ep.act_pos] = (uint8_t)action; run_log[ep.run_pos] = (uint8_t)action; }
+        ep.act_pos += 1; ep.n_act_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
       }
-      if (ep.status == EG_EP_OK) {
-        const State fin = state_of(a);
-        const double success = evaluate_impact(initial, fin);
-        if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
-          const double factor = 0.1 * success;
-          __syncthreads();
-          for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, sm, lane, sm.ydef[i], factor);
-        }
-      }
-    }
-    if (ep.status != EG_EP_OK) break;
-
-    // ---- additional actions (simulation.rs:144-198) ----
-    uint32_t n_add = 0;
-    if (replay) {
-      n_add = S.has_best_actions ? (uint32_t)(S.best_off[yi + 1] - S.best_off[yi]) : 0u;
-    } else {   // sampling.rs:380-443
-      const uint32_t dcount = (uint32_t)ep.n_def_y;
-      const uint32_t cap = dcount >= 20u ? 0u : 20u - dcount;
-      if (cap > 0u) {
-        const double u = rng_f64(rng, sm, lane);
-        if (S.cw != nullptr) {
-          const double* cw = S.cw + yi * EG_N_COUNTS;
-          double total = 0.0;
-          for (int c = 0; c < EG_N_COUNTS; ++c) total += cw[c];
-          if (total > 0.0) {
-            double v = u * total;
-            n_add = 5u < cap ? 5u : cap;
-            for (uint32_t c = 0; c < (uint32_t)EG_N_COUNTS; ++c) { v -= cw[c]; if (v <= 0.0) { n_add = c < cap ? c : cap; break; } }
-          }
-        } else {   // heuristic branch; min/max actions were evaluated on the host (sampling.rs:425-427)
-          const uint32_t hi = S.heur_max < cap ? S.heur_max : cap;
-          const uint32_t lo = S.heur_min < hi ? S.heur_min : hi;
-          n_add = lo == hi ? lo : lo + rng_range32(rng, sm, lane, hi - lo + 1u);
-        }
-      }
-    }
-    for (uint32_t k = 0; k < n_add && ep.status == EG_EP_OK; ++k) {
-      int action;
-      if (replay) {   // sampling.rs:78-145
-        if (S.has_best_actions) {
-          const int lo = S.best_off[yi], n = S.best_off[yi + 1] - lo;
-          if (replay_idx < n) { action = S.best_actions[lo + replay_idx]; replay_idx += 1; }
-          else action = smart_fallback(rng, sm, lane, year);
-        } else action = smart_fallback(rng, sm, lane, year);
-        push_run(action);
-      } else action = sample_action_weighted(S, rng, sm, lane);
-      apply(action);
-      if (ep.status != EG_EP_OK) break;
-      if (ep.act_pos >= EG_ACT_CAP) { ep.status = EG_EP_OVERFLOW; break; }
-      if (lane == 0) act_log[ep.act_pos] = (uint8_t)action;
-      ep.act_pos += 1; ep.n_act_y += 1;
-      push_run(action);   // simulation.rs:197
     }
     if (ep.status != EG_EP_OK) break;
     ep.bytes += 2.0 * (double)(ep.n_act_y + ep.n_def_y);
 
     // ---- yearly metrics (metrics_calculation.rs:32-175) ----
+    EG_T0();
     const State s = state_of(a);
     const double gen = (a.tg + a.ig) + a.sg;
     const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * T.carbon_price[yi];
@@ -573,7 +694,9 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
       O.n_act[(size_t)e * kYears + yi] = ep.n_act_y;
     }
     gcost_end = a.gcost; ocost_end = a.ocost;
+    co2_end = a.co2; tg_end = a.tg; ig_end = a.ig; sg_end = a.sg;
     last_net = s.net; last_opinion = s.opinion; last_capital = total_capital; last_balance = s.balance;
+    EG_T1(4);
   }
 
   if (lane == 0) {   // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
@@ -584,20 +707,25 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     O.status[e] = ep.status;
     O.n_gens[e] = ep.ngen;
     O.n_offsets[e] = ep.noff;
-    O.n_draws[e] = rng.words;
+    O.n_draws[e] = (unsigned long long)rng.words;
     O.bytes_moved[e] = ep.bytes;
+#ifdef EG_STAMPS
+    stamps[7] = __builtin_readcyclecounter() - t_begin;
+    // diagnostic build only: cycle shares go to the (otherwise unread) tail of this episode's act_log buffer
+    unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 64);
+    for (int i = 0; i < 8; ++i) dbg[i] = stamps[i];
+#endif
   }
 }
 
 // ---- B2: a single placement search, for parity tests of the arg-max --------------------------------------------
 __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, const uint16_t* __restrict__ cells,
                                                  int n_extra, int32_t* out_cell, double* out_score) {
-  __shared__ Smem sm;
   const int lane = threadIdx.x;
   for (int g = lane; g < n_extra; g += kWave) sm.gcell[g] = cells[g];
   __syncthreads();
   double score = 0.0;
-  const int cell = place_search(T, sm, lane, yi, type, n_extra, &score);
+  const int cell = place_search(T, lane, yi, type, n_extra, &score);
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
