@@ -2,6 +2,7 @@
 // There is no CPU execution path behind these entry points: without a HIP device eg_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -159,15 +160,36 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   up(H.usage, &D.usage); up(H.population, &D.population);
   up(H.pre_co2, &D.pre_co2); up(H.pre_tg, &D.pre_tg); up(H.pre_ig, &D.pre_ig); up(H.pre_sg, &D.pre_sg);
   up(H.pre_optot, &D.pre_optot); up(H.pre_opcnt, &D.pre_opcnt);
-  {  // te is re-strided for the device so that each slice can be read 16 B per lane
-    std::vector<double> te_dev(size_t(kYears) * kRadiusClasses * kTeStride, 0.0);
-    for (int s = 0; s < kYears * kRadiusClasses; ++s)
-      std::memcpy(&te_dev[size_t(s) * kTeStride], &H.te[size_t(s) * kCells], sizeof(double) * kCells);
-    up(te_dev, &D.te);
-  }
-  {  // one pad element: the arg-max scan reads coastf 16 B at a time
-    std::vector<double> cf(H.coastf); cf.push_back(0.0); cf.push_back(0.0);
-    up(cf, &D.coastf);
+  {  // Sorted candidate lists.  final(c) = ((te[c] * prod_g d/R) * cf[c]) * size <= base(c) = (te[c] * cf[c]) * size
+     // because every factor is in [0, 1] and IEEE multiplication is monotone, so a scan in descending base order can
+     // stop as soon as the next base is below the best final score found (k_rollout / place_search).
+    std::vector<std::pair<int, int>> variants;   // (radius class, marine)
+    std::vector<int32_t> variant_of(kTypes, 0);
+    for (int t = 0; t < kTypes; ++t) {
+      std::pair<int, int> key(H.rclass[t], H.marine[t] ? 1 : 0);
+      size_t v = 0;
+      while (v < variants.size() && variants[v] != key) ++v;
+      if (v == variants.size()) variants.push_back(key);
+      variant_of[t] = int32_t(v);
+    }
+    const int NV = int(variants.size());
+    std::vector<uint16_t> ps_cell(size_t(kYears) * NV * kPsStride, 0);
+    std::vector<double> ps_te(size_t(kYears) * NV * kPsStride, 0.0), ps_cf(size_t(kYears) * NV * kPsStride, 1.0);
+    std::vector<double> base(kCells);
+    std::vector<int> order(kCells);
+    for (int y = 0; y < kYears; ++y)
+      for (int v = 0; v < NV; ++v) {
+        const double* te = &H.te[(size_t(y) * kRadiusClasses + variants[v].first) * kCells];
+        const bool marine = variants[v].second != 0;
+        for (int c = 0; c < kCells; ++c) { base[c] = (te[c] * (marine ? H.coastf[c] : 1.0)) * H.size_factor; order[c] = c; }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return base[a] > base[b]; });
+        const size_t o = (size_t(y) * NV + v) * kPsStride;
+        for (int r = 0; r < kCells; ++r) {
+          ps_cell[o + r] = uint16_t(order[r]); ps_te[o + r] = te[order[r]]; ps_cf[o + r] = marine ? H.coastf[order[r]] : 1.0;
+        }
+      }
+    up(ps_cell, &D.ps_cell); up(ps_te, &D.ps_te); up(ps_cf, &D.ps_cf); up(variant_of, &D.variant);
+    D.n_variants = NV;
   }
   up(H.dr, &D.dr);
   up(H.m03, &D.m03); up(H.t12, &D.t12); up(H.cc, &D.cc); up(H.out_mw, &D.out_mw); up(H.co2_t, &D.co2_t);

@@ -16,7 +16,8 @@ constexpr int kRadiusClasses = 6;
 constexpr int kMaxReach = 12;   // cells; the largest penalty radius is 12 km
 constexpr int kMults = 3;
 constexpr int kOffsetTypes = 4;
-constexpr int kTeStride = 2608;   // device copy of te: every [year][class] slice starts 64 B aligned (2601 -> 2608 doubles)
+constexpr int kPsStride = 2624;   // sorted candidate lists on the device: 41 chunks of 64 (2601 -> 2624 entries)
+constexpr int kMaxVariants = 12;  // distinct (radius class, marine) pairs over the 15 types (8 for the reference's types)
 
 // Policy-independent tables, built once per world on the host (eg_tables.cpp) and mirrored in HBM.
 // Everything a kernel needs that involves sqrt / division by data / pow / exp lives here, so device code only
@@ -59,7 +60,11 @@ struct DevTables {
   const double* usage; const double* population;
   const double* pre_co2; const double* pre_tg; const double* pre_ig; const double* pre_sg; const double* pre_optot;
   const int32_t* pre_opcnt;
-  const double* te; const double* coastf; const double* dr; double size_factor;
+  // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
+  const uint16_t* ps_cell; const double* ps_te; const double* ps_cf;   // [26][n_variants][kPsStride]
+  const int32_t* variant;   // [15] type -> variant
+  int32_t n_variants;
+  const double* dr; double size_factor;
   const double* m03; const double* t12; const double* cc;
   const double* out_mw; const double* co2_t;
   const int32_t* cls; const int32_t* rclass; const int32_t* marine; const int32_t* reach;

@@ -38,7 +38,8 @@ __constant__ int c_deficit_type[14] = {8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13
 __constant__ int c_deficit_slot[15] = {5, 6, 10, 11, 7, 9, -1, 1, 0, 4, 8, 3, 2, 12, 13};
 
 struct __align__(16) Smem {
-  double fld[kCells + 1];             // placement score field of the current search (+1: filled 16 B at a time)
+  double dr[kRadiusClasses * 169];    // d/R by (|di|, |dj|) for every radius class; 1.0 where d >= R
+  double scaled[64];                  // stalled sampler: weights^p in sorted order
   double w[64];                       // this year's main weights (61 used)
   double dw[16];                      // this year's deficit weights (15 used)
   double cw[24];                      // this year's action-count weights (21 used)
@@ -51,7 +52,7 @@ struct __align__(16) Smem {
   uint8_t ydef[192];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
                                       // [128,192) sort permutation of the stalled sampler
 };
-static_assert(sizeof(Smem) <= 27306, "six episodes per CU need <= 160 KiB / 6 of LDS each");
+static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
@@ -178,107 +179,67 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 }
 
 // ---- placement: arg-max over the 51x51 distinct candidates (Q10) -------------------------------------------
-// fld[c] starts from te[year][class][c] (settlement product, then existing plant, in list order), is multiplied by
-// d/R for every generator added so far in list order, then by the coast factor (marine types) and the size
-// factor.  Strict '>' against a running best that starts at 0.0, candidates in (i, j) order: first maximum wins.
-//
-// Lane l owns box position l + 64*p of the (2*reach+1)^2 penalty box in pass p; its offset (di, dj) and factor d/R do
-// not depend on the generator, so they sit in registers for the whole search and the generator loop is one LDS
-// read-modify-write per pass.  A wave's LDS operations execute in program order, so consecutive generators need no
-// barrier between them even when their boxes overlap.
+// Reference (metal_location_search.rs:110-176): score(c) = ((te[c] * prod_{g in list order, d<R} d/R) * coast(c)) * 0.9,
+// keep the first strictly greater score in (i, j) order, i.e. the maximum with ties to the lowest cell index.
+// Here the candidates of (year, radius class, marine) come pre-sorted by their unpenalised score (host, eg_api.cpp).
+// Every penalty factor is in [0, 1] and IEEE multiplication is monotone, so score(c) <= base(c): the scan takes 64
+// candidates at a time (one per lane, each lane folding the generator list in order for its own cell) and stops as
+// soon as the next chunk's largest base score is below the best score found — the same winner, bit for bit, as the
+// exhaustive search, usually after one or two chunks.
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-template <int NPASS>
-__device__ __forceinline__ void apply_generator_penalties(int lane, int reach, const double* __restrict__ dr, int ngen) {
-  const int side = 2 * reach + 1, box = side * side;
-  double f[NPASS]; int off[NPASS];   // off: di | dj << 8 (biased by 16), or -1 when the lane has no box cell in this pass
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int idx = lane + kWave * p;
-    const int bi = idx / side, bj = idx - bi * side;
-    const int di = bi - reach, dj = bj - reach;
-    const bool valid = idx < box;
-    const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
-    f[p] = valid ? dr[adi * 13 + adj] : 1.0;
-    off[p] = valid ? ((di + 16) | ((dj + 16) << 8)) : -1;
-  }
-  for (int g = 0; g < ngen; ++g) {
-    const int gc = sm.gcell[g] & 0xFFF;
-    const int gi = gc / kGrid, gj = gc - gi * kGrid;
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      const int ci = gi + (off[p] & 0xFF) - 16, cj = gj + ((off[p] >> 8) & 0xFF) - 16;
-      if (off[p] >= 0 && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {
-        const int c = ci * kGrid + cj;
-        sm.fld[c] = sm.fld[c] * f[p];
-      }
-    }
-  }
-}
-
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score) {
+  const int v = T.variant[type];
   const int rc = T.rclass[type];
-  {   // field <- te[yi][rc][:], 16 B per lane per load, all 21 loads in flight before the first LDS store
-    const double2* te2 = reinterpret_cast<const double2*>(T.te + ((size_t)yi * kRadiusClasses + rc) * kTeStride);
-    double2* f2 = reinterpret_cast<double2*>(sm.fld);
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {       // three groups of seven loads in flight
-      double2 v[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) { const int i = lane + kWave * (7 * h + k); v[k] = i < (kCells + 1) / 2 ? te2[i] : make_double2(0.0, 0.0); }
-#pragma unroll
-      for (int k = 0; k < 7; ++k) { const int i = lane + kWave * (7 * h + k); if (i < (kCells + 1) / 2) f2[i] = v[k]; }
-    }
-  }
-  __syncthreads();
   const int reach = T.reach[rc];
-  const double* dr = T.dr + (size_t)rc * 169;
-  if (ngen > 0) {
-    switch (reach) {   // passes = ceil((2*reach+1)^2 / 64)
-      case 2: apply_generator_penalties<1>(lane, reach, dr, ngen); break;    // 3 km:  25 cells
-      case 4: apply_generator_penalties<2>(lane, reach, dr, ngen); break;    // 5 km:  81
-      case 5: apply_generator_penalties<2>(lane, reach, dr, ngen); break;    // 6 km: 121
-      case 6: apply_generator_penalties<3>(lane, reach, dr, ngen); break;    // 7 km: 169
-      case 7: apply_generator_penalties<4>(lane, reach, dr, ngen); break;    // 8 km: 225
-      default: apply_generator_penalties<9>(lane, reach, dr, ngen); break;   // 12 km: 529
-    }
-  }
-  __syncthreads();
-  const bool marine = T.marine[type] != 0;
+  const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
+  const uint16_t* __restrict__ cells = T.ps_cell + o;
+  const double* __restrict__ tes = T.ps_te + o;
+  const double* __restrict__ cfs = T.ps_cf + o;
+  const double* dr = sm.dr + rc * 169;
+  const double size_factor = T.size_factor;
+  const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   double best = 0.0; int best_c = kCells;
-  {   // lane l scans cells 2i, 2i+1 for i = l + 64k: ascending within the lane, so a strict '>' keeps the first maximum
-    const double2* f2 = reinterpret_cast<const double2*>(sm.fld);
-    const double2* cf2 = reinterpret_cast<const double2*>(T.coastf);
-#pragma unroll 7
-    for (int k = 0; k < 21; ++k) {
-      const int i = lane + kWave * k;
-      if (i < (kCells + 1) / 2) {
-        double2 sv = f2[i];
-        if (marine) { const double2 cf = cf2[i]; sv.x = sv.x * cf.x; sv.y = sv.y * cf.y; }
-        sv.x = sv.x * T.size_factor; sv.y = sv.y * T.size_factor;
-        if (sv.x > best) { best = sv.x; best_c = 2 * i; }
-        if (2 * i + 1 < kCells && sv.y > best) { best = sv.y; best_c = 2 * i + 1; }
+  for (int chunk = 0; chunk < (kCells + kWave - 1) / kWave; ++chunk) {
+    const int r = chunk * kWave + lane;
+    const double te = tes[r];                 // padded with 0.0 beyond the 2601 candidates
+    const double cf = cfs[r];
+    const int cell = cells[r];
+    const double base = (te * cf) * size_factor;
+    if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
+    const int ci = cell / kGrid, cj = cell - ci * kGrid;
+    double s = te;
+    for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
+      const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : 0;
+      const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+      for (int j = 0; j < cnt; ++j) {
+        const int gc = __builtin_amdgcn_readlane(mine, j);
+        const int gi = gc / kGrid, gj = gc - gi * kGrid;
+        int di = ci - gi, dj = cj - gj;
+        di = di < 0 ? -di : di; dj = dj < 0 ? -dj : dj;
+        if (di <= reach && dj <= reach) s = s * dr[di * 13 + dj];
       }
     }
-  }
-  double wmax = best;
+    s = (s * cf) * size_factor;
+    if (r >= kCells) s = 0.0;
+    if (__any(s > best || (s == best && s > 0.0 && cell < best_c))) {
+      double wmax = s;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { const double other = __shfl_xor(wmax, o); wmax = other > wmax ? other : wmax; }
-  const unsigned long long holders = __ballot(best == wmax);
-  int win_c;
-  if (__popcll(holders) == 1) {
-    win_c = __builtin_amdgcn_readlane(best_c, __ffsll((long long)holders) - 1);
-  } else {                        // equal maxima in several lanes: the lowest cell index is the first in (i, j) order
-    win_c = best == wmax ? best_c : kCells;
+      for (int sh = 32; sh >= 1; sh >>= 1) { const double other = __shfl_xor(wmax, sh); wmax = other > wmax ? other : wmax; }
+      int win_c = s == wmax ? cell : kCells;
+      const unsigned long long holders = __ballot(s == wmax);
+      if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell, __ffsll((long long)holders) - 1);
+      else {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(win_c, o); win_c = other < win_c ? other : win_c; }
+        for (int sh = 32; sh >= 1; sh >>= 1) { const int other = __shfl_xor(win_c, sh); win_c = other < win_c ? other : win_c; }
+      }
+      if (wmax > best || (wmax == best && win_c < best_c)) { best = wmax; best_c = win_c; }
+    }
   }
-  __syncthreads();
-  if (best_score) *best_score = wmax;
-  return wmax > 0.0 ? win_c : -1;
+  if (best_score) *best_score = best;
+  return best > 0.0 ? best_c : -1;
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
@@ -357,17 +318,17 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, int lane) { 
       int rank = 0;
 #pragma unroll 4
       for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
-      sm.fld[rank] = eg_detpow(mine, power);
+      sm.scaled[rank] = eg_detpow(mine, power);
       sm.ydef[128 + rank] = (uint8_t)lane;
     }
     __syncthreads();
     double total_scaled = 0.0;
 #pragma unroll 4
-    for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.fld[i];
+    for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
     double v = rng_f64(r, lane) * total_scaled;
     int pick = sm.ydef[128];
 #pragma unroll 4
-    for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.fld[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
+    for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.scaled[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
     __syncthreads();
     return pick;
   }
@@ -418,6 +379,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
   Rng rng;
   rng_seed(rng, seed + first_index + (unsigned long long)e, lane);   // simulation.rs:50-53, one stream per episode
 
@@ -723,6 +685,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
                                                  int n_extra, int32_t* out_cell, double* out_score) {
   const int lane = threadIdx.x;
   for (int g = lane; g < n_extra; g += kWave) sm.gcell[g] = cells[g];
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
   __syncthreads();
   double score = 0.0;
   const int cell = place_search(T, lane, yi, type, n_extra, &score);
