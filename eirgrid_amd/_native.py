@@ -12,6 +12,8 @@ YEARS, N_ACTIONS, N_DEFICIT, N_COUNTS, N_TYPES = 26, 61, 15, 21, 15
 GRID, CELLS, YEARLY_FIELDS = 51, 2601, 21
 MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 1024, 1024, 2048, 1024, 1024
 STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
+CANDIDATE_BYTES = 8 + 8 + 32 + 4 * YEARS + 4 * YEARS + RUN_CAP + DEF_CAP
+PACKET_BYTES = 8 * STATS_LEN + CANDIDATE_BYTES
 
 EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 
@@ -54,7 +56,7 @@ class EgEpisodeOut(C.Structure):
 # every symbol include/eirgrid_hip.h declares
 EXPORTS = [
     "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
-    "eg_rollout_launch", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
+    "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
     "eg_fetch_episode_lists", "eg_place", "eg_policy_apply_reduced",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
@@ -84,6 +86,8 @@ def lib():
     L.eg_upload_snapshot.argtypes = [C.c_void_p, C.POINTER(EgPolicySnapshot), C.POINTER(EgOpts)]
     L.eg_rollout_launch.restype = C.c_int32
     L.eg_rollout_launch.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, _u8p]
+    L.eg_rollout_launch_update.restype = C.c_int32
+    L.eg_rollout_launch_update.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, _u8p, C.c_void_p]
     L.eg_sync.restype = C.c_int32
     L.eg_sync.argtypes = [C.c_void_p]
     L.eg_fetch.restype = C.c_int32

@@ -53,12 +53,9 @@ struct eg_ctx {
   std::vector<void*> allocs;        // table allocations
   DevTables dev{};
   // snapshot in HBM
-  double *d_w = nullptr, *d_dw = nullptr, *d_cw = nullptr;
-  int32_t *d_best_off = nullptr, *d_bestd_off = nullptr;
-  uint8_t *d_best = nullptr, *d_bestd = nullptr;
-  unsigned long long *d_best_mask = nullptr, *d_bestd_mask = nullptr;
+  // the whole snapshot lives in ONE device buffer filled by ONE copy from a pinned staging buffer
+  uint8_t* d_snap = nullptr; uint8_t* h_snap = nullptr;
   StatsParams stats_params{};
-  size_t best_cap = 0, bestd_cap = 0;
   DevSnapshot snap{};
   bool snap_valid = false;
   // outputs
@@ -72,6 +69,19 @@ struct eg_ctx {
 };
 
 namespace {
+
+// byte offsets inside the packed snapshot buffer
+constexpr size_t kSnapW = 0;
+constexpr size_t kSnapDw = kSnapW + sizeof(double) * EG_YEARS * EG_N_ACTIONS;
+constexpr size_t kSnapCw = kSnapDw + sizeof(double) * EG_YEARS * EG_N_DEFICIT;
+constexpr size_t kSnapMask = kSnapCw + sizeof(double) * EG_YEARS * EG_N_COUNTS;
+constexpr size_t kSnapDmask = kSnapMask + 8 * EG_YEARS;
+constexpr size_t kSnapOff = kSnapDmask + 8 * EG_YEARS;
+constexpr size_t kSnapOffd = kSnapOff + 4 * 28;
+constexpr size_t kSnapBest = kSnapOffd + 4 * 28;
+constexpr size_t kSnapBestCap = 4096;     // best_actions can hold every replay-doubled year list
+constexpr size_t kSnapBestd = kSnapBest + kSnapBestCap;
+constexpr size_t kSnapBytes = kSnapBestd + kSnapBestCap;
 
 template <typename T>
 int upload_vec(eg_ctx* c, const std::vector<T>& v, const T** dst) {
@@ -198,12 +208,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   D.size_factor = H.size_factor; D.n_existing = world->n_existing;
   if (rc == EG_OK && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
   if (rc == EG_OK) {
-    size_t wb = sizeof(double) * EG_YEARS * EG_N_ACTIONS, db = sizeof(double) * EG_YEARS * EG_N_DEFICIT, cb = sizeof(double) * EG_YEARS * EG_N_COUNTS;
-    if (hipMalloc((void**)&c->d_w, wb) != hipSuccess || hipMalloc((void**)&c->d_dw, db) != hipSuccess ||
-        hipMalloc((void**)&c->d_cw, cb) != hipSuccess || hipMalloc((void**)&c->d_best_off, 27 * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_bestd_off, 27 * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->d_best_mask, 26 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void**)&c->d_bestd_mask, 26 * sizeof(unsigned long long)) != hipSuccess) { set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP; }
+    if (hipMalloc((void**)&c->d_snap, kSnapBytes) != hipSuccess || hipHostMalloc((void**)&c->h_snap, kSnapBytes) != hipSuccess) {
+      set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
+    }
   }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
@@ -214,8 +221,9 @@ void eg_destroy(eg_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
-  void* snap[] = {c->d_w, c->d_dw, c->d_cw, c->d_best_off, c->d_bestd_off, c->d_best, c->d_bestd, c->d_mask, c->d_best_mask, c->d_bestd_mask};
-  for (void* p : snap) if (p) (void)hipFree(p);
+  if (c->d_snap) (void)hipFree(c->d_snap);
+  if (c->h_snap) (void)hipHostFree(c->h_snap);
+  if (c->d_mask) (void)hipFree(c->d_mask);
   free_outputs(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -249,12 +257,29 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   if (!c || !s || !s->weights || !s->deficit_weights) { set_error("eg_upload_snapshot: bad argument"); return EG_ERR_BAD_ARG; }
   if (o && o->enable_construction_delays) { set_error("enable_construction_delays is not implemented on the device (SURVEY §8(f) N4)"); return EG_ERR_UNSUPPORTED; }
   EG_HIP(hipSetDevice(c->device));
-  EG_HIP(hipMemcpy(c->d_w, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS, hipMemcpyHostToDevice));
-  EG_HIP(hipMemcpy(c->d_dw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT, hipMemcpyHostToDevice));
-  if (s->count_weights) EG_HIP(hipMemcpy(c->d_cw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS, hipMemcpyHostToDevice));
+  const bool have_lists = s->has_best && s->best_count && s->best_actions && s->best_deficit_count && s->best_deficit_actions;
+  int32_t off[28] = {0}, offd[28] = {0};
+  if (have_lists) for (int y = 0; y < EG_YEARS; ++y) { off[y + 1] = off[y] + s->best_count[y]; offd[y + 1] = offd[y] + s->best_deficit_count[y]; }
+  if (size_t(off[26]) > kSnapBestCap || size_t(offd[26]) > kSnapBestCap) { set_error("eg_upload_snapshot: best action lists too long"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipStreamSynchronize(nullptr));   // the pinned staging buffer may still feed the previous copy
+  uint8_t* h = c->h_snap;
+  std::memcpy(h + kSnapW, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
+  std::memcpy(h + kSnapDw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT);
+  if (s->count_weights) std::memcpy(h + kSnapCw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS);
+  unsigned long long mask[26] = {0}, dmask[26] = {0};
+  if (have_lists)
+    for (int y = 0; y < EG_YEARS; ++y) {
+      for (int i = off[y]; i < off[y + 1]; ++i) if (s->best_actions[i] < 64) mask[y] |= 1ull << s->best_actions[i];
+      for (int i = offd[y]; i < offd[y + 1]; ++i) if (s->best_deficit_actions[i] < 64) { mask[y] |= 1ull << s->best_deficit_actions[i]; dmask[y] |= 1ull << s->best_deficit_actions[i]; }
+    }
+  std::memcpy(h + kSnapMask, mask, sizeof(mask)); std::memcpy(h + kSnapDmask, dmask, sizeof(dmask));
+  std::memcpy(h + kSnapOff, off, sizeof(off)); std::memcpy(h + kSnapOffd, offd, sizeof(offd));
+  if (have_lists) { std::memcpy(h + kSnapBest, s->best_actions, size_t(off[26])); std::memcpy(h + kSnapBestd, s->best_deficit_actions, size_t(offd[26])); }
+  EG_HIP(hipMemcpyAsync(c->d_snap, h, kSnapBytes, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
   DevSnapshot& S = c->snap;
   S = DevSnapshot{};
-  S.w = c->d_w; S.dw = c->d_dw; S.cw = s->count_weights ? c->d_cw : nullptr;
+  S.w = reinterpret_cast<const double*>(c->d_snap + kSnapW); S.dw = reinterpret_cast<const double*>(c->d_snap + kSnapDw);
+  S.cw = s->count_weights ? reinterpret_cast<const double*>(c->d_snap + kSnapCw) : nullptr;
   S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
   S.has_best = s->has_best ? 1 : 0;
   // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)
@@ -265,31 +290,11 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   S.noop_boost = (s->has_best && s->best_metrics[0] <= 0.0 && s->best_metrics[2] > 50000000000.0 * 8.0) ? 1 : 0;   // learning.rs:82
   const double scaled = std::pow(s->exploration_rate, 0.5);   // sampling.rs:425-427
   S.heur_min = uint32_t(std::round(2.0 / scaled)); S.heur_max = uint32_t(std::round(12.0 / scaled));
-  const bool have_lists = s->has_best && s->best_count && s->best_actions && s->best_deficit_count && s->best_deficit_actions;
   S.has_best_actions = have_lists ? 1 : 0; S.has_best_deficit = have_lists ? 1 : 0;
-  int32_t off[27] = {0}, offd[27] = {0};
-  if (have_lists) for (int y = 0; y < EG_YEARS; ++y) { off[y + 1] = off[y] + s->best_count[y]; offd[y + 1] = offd[y] + s->best_deficit_count[y]; }
-  EG_HIP(hipMemcpy(c->d_best_off, off, sizeof(off), hipMemcpyHostToDevice));
-  EG_HIP(hipMemcpy(c->d_bestd_off, offd, sizeof(offd), hipMemcpyHostToDevice));
-  auto put = [&](uint8_t** d, size_t* cap, const uint8_t* src, size_t n) -> int {
-    if (n + 1 > *cap) { if (*d) (void)hipFree(*d); *d = nullptr; EG_HIP(hipMalloc((void**)d, n + 64)); *cap = n + 64; }
-    if (n) EG_HIP(hipMemcpy(*d, src, n, hipMemcpyHostToDevice));
-    return EG_OK;
-  };
-  int rc = put(&c->d_best, &c->best_cap, have_lists ? s->best_actions : nullptr, have_lists ? size_t(off[26]) : 0);
-  if (rc != EG_OK) return rc;
-  rc = put(&c->d_bestd, &c->bestd_cap, have_lists ? s->best_deficit_actions : nullptr, have_lists ? size_t(offd[26]) : 0);
-  if (rc != EG_OK) return rc;
-  S.best_off = c->d_best_off; S.best_actions = c->d_best; S.bestd_off = c->d_bestd_off; S.bestd_actions = c->d_bestd;
-  unsigned long long mask[26] = {0}, dmask[26] = {0};
-  if (have_lists)
-    for (int y = 0; y < EG_YEARS; ++y) {
-      for (int i = off[y]; i < off[y + 1]; ++i) if (s->best_actions[i] < 64) mask[y] |= 1ull << s->best_actions[i];
-      for (int i = offd[y]; i < offd[y + 1]; ++i) if (s->best_deficit_actions[i] < 64) { mask[y] |= 1ull << s->best_deficit_actions[i]; dmask[y] |= 1ull << s->best_deficit_actions[i]; }
-    }
-  EG_HIP(hipMemcpy(c->d_best_mask, mask, sizeof(mask), hipMemcpyHostToDevice));
-  EG_HIP(hipMemcpy(c->d_bestd_mask, dmask, sizeof(dmask), hipMemcpyHostToDevice));
-  S.best_mask = c->d_best_mask; S.bestd_mask = c->d_bestd_mask;
+  S.best_off = reinterpret_cast<const int32_t*>(c->d_snap + kSnapOff); S.bestd_off = reinterpret_cast<const int32_t*>(c->d_snap + kSnapOffd);
+  S.best_actions = c->d_snap + kSnapBest; S.bestd_actions = c->d_snap + kSnapBestd;
+  S.best_mask = reinterpret_cast<const unsigned long long*>(c->d_snap + kSnapMask);
+  S.bestd_mask = reinterpret_cast<const unsigned long long*>(c->d_snap + kSnapDmask);
   {  // learning.rs:134-180: everything of the contrast step that depends only on the snapshot
     StatsParams& P = c->stats_params;
     const double k = double(s->iterations_without_improvement);
@@ -321,11 +326,36 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
   EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, nullptr);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, nullptr, nullptr);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
   c->last_n = n;
+  return EG_OK;
+}
+
+int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, const uint8_t* replay_mask, void* d_packet) {
+  if (!c || !c->snap_valid || !d_packet) { set_error("eg_rollout_launch_update: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  int rc = ensure_outputs(c, n ? n : 1);
+  if (rc != EG_OK) return rc;
+  const uint8_t* d_mask = nullptr;
+  if (replay_mask && n) {
+    if (n > c->mask_cap) { if (c->d_mask) (void)hipFree(c->d_mask); c->d_mask = nullptr; EG_HIP(hipMalloc((void**)&c->d_mask, n)); c->mask_cap = n; }
+    EG_HIP(hipMemcpyAsync(c->d_mask, replay_mask, n, hipMemcpyHostToDevice, nullptr));
+    d_mask = c->d_mask;
+  }
+  rc = collect_timing(c);
+  if (rc != EG_OK) return rc;
+  EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
+  EG_HIP(hipEventRecord(c->ev0, nullptr));
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, (long long*)d_packet, nullptr);
+  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  EG_HIP(hipEventRecord(c->ev1, nullptr));
+  c->timing_pending = true;
+  c->last_n = n;
+  lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
+  if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
 

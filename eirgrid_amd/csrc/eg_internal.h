@@ -110,8 +110,10 @@ struct DevOut {
 void set_error(const std::string& s);
 
 // launchers implemented in eg_rollout.hip
+struct StatsParams;
+struct UpdateCandidate;
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, void* stream);
+                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180), evaluated on the host
@@ -124,5 +126,15 @@ struct StatsParams {
   double stagnation;     // learning.rs:163-164
 };
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream);
+// best episode of a batch, laid out right behind the statistics in the update packet (eg_rollout_launch_update)
+struct UpdateCandidate {
+  double score;            // -1 when the batch has no successful episode
+  long long index;         // global episode index
+  double metrics[4];
+  int32_t n_run[EG_YEARS], n_def[EG_YEARS];
+  uint8_t run_log[EG_RUN_CAP], def_log[EG_DEF_CAP];
+};
+static_assert(sizeof(UpdateCandidate) == EG_CANDIDATE_BYTES, "candidate layout is part of the C ABI");
+int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCandidate* d_cand, void* stream);
 
 }  // namespace eg

@@ -358,6 +358,70 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   double bytes;
 };
 
+// ---- batch ("reduced") update statistics --------------------------------------------------------------------
+// The reference applies apply_contrast_learning / apply_deficit_contrast_learning one episode at a time under a lock
+// (multi_simulation.rs:494-508).  For a batch that shares one snapshot the same multiplicative nudges are
+// accumulated in log space, as integers (Q32 fixed point), so the result does not depend on the order in which
+// episodes, workgroups or ranks contribute: one sum all-reduce of this buffer is the whole exchange (SURVEY §8(e)).
+//   stats[0] episodes ok   [1] episodes failed   [2] episodes that qualify for contrast (learning.rs:160)
+//   stats[8 + (y*61+a)]              Σ Q32 ln(penalty_factor)  over occurrences of a in year y that are absent from best
+//   stats[8 + 26*61 + (y*61+a)]      Σ Q32 ln(mild_penalty)    over right-action-wrong-slot occurrences (learning.rs:241-251)
+//   stats[8 + 2*26*61 + (y*15+s)]    number of deficit actions of slot s in year y absent from best_deficit_actions[y]
+constexpr int kStatsMain = EG_YEARS * EG_N_ACTIONS;
+constexpr double kQ32 = 4294967296.0;
+
+__device__ double device_score(const double* m) {   // ai/metrics/scoring.rs:18-44 (mode None)
+  if (m[0] > 0.0) return 1.0 - dmin(m[0] / 1000000.0, 1.0);
+  const double normalized_cost = dmax(m[2] / kMaxCost, 1.0);
+  const double cost_score = 1.0 - dmin(log(normalized_cost) / log(kMaxCost * 100.0 / kMaxCost), 1.0);
+  const double cost_weight = normalized_cost > 8.0 ? 0.8 : 0.5;
+  return 1.0 + (cost_score * cost_weight + m[1] * (1.0 - cost_weight));
+}
+
+// One wave adds the contributions of episode e (its outputs must be visible in memory).
+__device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats) {
+  unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
+  if (O.status[e] != EG_EP_OK) {
+    if (lane == 0) { atomicAdd(&st[1], 1ull); O.score[e] = -1.0; }
+    return;
+  }
+  const double score = device_score(O.metrics + (size_t)e * 4);
+  if (lane == 0) { atomicAdd(&st[0], 1ull); O.score[e] = score; }
+  if (!P.has_best) return;
+  const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
+  const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
+  unsigned long long q_pen = 0, q_mild = 0;
+  if (qualifies) {
+    if (lane == 0) atomicAdd(&st[2], 1ull);
+    const double combined = pow(det, 0.3) * P.stagnation;                                            // learning.rs:168-171
+    q_pen = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);    // learning.rs:177
+    q_mild = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);   // learning.rs:247
+  }
+  const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
+  const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
+  int rp = 0, dp = 0;
+  for (int y = 0; y < EG_YEARS; ++y) {
+    const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
+    const unsigned long long mask = S.best_mask[y], dmask = S.bestd_mask[y];
+    const int b0 = S.best_off[y], nb = S.best_off[y + 1] - b0, d0 = S.bestd_off[y], nbd = S.bestd_off[y + 1] - d0;
+    for (int j = lane; j < nr + nd; j += kWave) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
+      const int a = j < nr ? run[rp + j] : def[dp + (j - nr)];
+      if (qualifies) {
+        if (!((mask >> a) & 1ull)) atomicAdd(&st[8 + y * EG_N_ACTIONS + a], q_pen);
+        else if (j < nb + nbd) {
+          const int b = j < nb ? S.best_actions[b0 + j] : S.bestd_actions[d0 + (j - nb)];
+          if (a != b) atomicAdd(&st[8 + kStatsMain + y * EG_N_ACTIONS + a], q_mild);
+        }
+      }
+      if (j >= nr && !((dmask >> a) & 1ull)) {        // learning.rs:346-352
+        const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
+        if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
+      }
+    }
+    rp += nr; dp += nd;
+  }
+}
+
 #ifdef EG_STAMPS
 #define EG_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
 #define EG_T1(slot) stamps[slot] += __builtin_readcyclecounter() - t0_
@@ -368,7 +432,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
 
 __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
                                                    unsigned long long first_index, uint32_t n_episodes,
-                                                   const uint8_t* __restrict__ replay_mask) {
+                                                   const uint8_t* __restrict__ replay_mask, StatsParams P, long long* stats) {
   const int lane = threadIdx.x;
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
@@ -678,6 +742,11 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     for (int i = 0; i < 8; ++i) dbg[i] = stamps[i];
 #endif
   }
+  if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes
+    __threadfence();
+    __syncthreads();
+    episode_update_stats(O, S, P, e, lane, stats);
+  }
 }
 
 // ---- B2: a single placement search, for parity tests of the arg-max --------------------------------------------
@@ -692,95 +761,49 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
-// ---- batch ("reduced") update statistics --------------------------------------------------------------------
-// The reference applies apply_contrast_learning / apply_deficit_contrast_learning one episode at a time under a lock
-// (multi_simulation.rs:494-508).  For a batch that shares one snapshot the same multiplicative nudges are
-// accumulated here in log space, as integers (Q32 fixed point), so the result does not depend on the order in which
-// episodes, workgroups or ranks contribute: one sum all-reduce of this buffer is the whole exchange (SURVEY §8(e)).
-//   stats[0] episodes ok   [1] episodes failed   [2] episodes that qualify for contrast (learning.rs:160)
-//   stats[8 + (y*61+a)]              Σ Q32 ln(penalty_factor)  over occurrences of a in year y that are absent from best
-//   stats[8 + 26*61 + (y*61+a)]      Σ Q32 ln(mild_penalty)    over right-action-wrong-slot occurrences (learning.rs:241-251)
-//   stats[8 + 2*26*61 + (y*15+s)]    number of deficit actions of slot s in year y absent from best_deficit_actions[y]
-constexpr int kStatsMain = EG_YEARS * EG_N_ACTIONS;
-constexpr int kStatsBins = 2 * kStatsMain + EG_YEARS * EG_N_DEFICIT;
-constexpr double kQ32 = 4294967296.0;
-
-__device__ double device_score(const double* m) {   // ai/metrics/scoring.rs:18-44 (mode None)
-  if (m[0] > 0.0) return 1.0 - dmin(m[0] / 1000000.0, 1.0);
-  const double normalized_cost = dmax(m[2] / kMaxCost, 1.0);
-  const double cost_score = 1.0 - dmin(log(normalized_cost) / log(kMaxCost * 100.0 / kMaxCost), 1.0);
-  const double cost_weight = normalized_cost > 8.0 ? 0.8 : 0.5;
-  return 1.0 + (cost_score * cost_weight + m[1] * (1.0 - cost_weight));
+// statistics of a finished batch without re-running it (same accumulation as the k_rollout epilogue)
+__global__ void __launch_bounds__(kWave) k_update_stats(DevOut O, DevSnapshot S, StatsParams P, uint32_t n, long long* stats) {
+  const uint32_t e = blockIdx.x;
+  if (e >= n) return;
+  episode_update_stats(O, S, P, e, threadIdx.x, stats);
 }
 
-__global__ void __launch_bounds__(256) k_update_stats(DevOut O, DevSnapshot S, StatsParams P, uint32_t n, long long* stats) {
-  __shared__ long long h[kStatsBins];
-  __shared__ long long head[4];
-  for (int i = threadIdx.x; i < kStatsBins; i += blockDim.x) h[i] = 0;
-  if (threadIdx.x < 4) head[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) {
-    if (O.status[e] != EG_EP_OK) {
-      atomicAdd((unsigned long long*)&head[1], 1ull);
-      O.score[e] = -1.0;
-    } else {
-      atomicAdd((unsigned long long*)&head[0], 1ull);
-      const double score = device_score(O.metrics + (size_t)e * 4);
-      O.score[e] = score;
-      const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
-      const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
-      if (P.has_best) {
-        const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
-        const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
-        long long q_pen = 0, q_mild = 0;
-        if (qualifies) {
-          atomicAdd((unsigned long long*)&head[2], 1ull);
-          const double combined = pow(det, 0.3) * P.stagnation;                        // learning.rs:168-171
-          q_pen = llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);     // learning.rs:177
-          q_mild = llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);    // learning.rs:247
-        }
-        int rp = 0, dp = 0;
-        for (int y = 0; y < EG_YEARS; ++y) {
-          const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
-          if (qualifies) {
-            const unsigned long long mask = S.best_mask[y];
-            const int b0 = S.best_off[y], nb = S.best_off[y + 1] - b0, d0 = S.bestd_off[y], nbd = S.bestd_off[y + 1] - d0;
-            for (int j = 0; j < nr + nd; ++j) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
-              const int a = j < nr ? run[rp + j] : def[dp + (j - nr)];
-              if (!((mask >> a) & 1ull)) atomicAdd((unsigned long long*)&h[y * EG_N_ACTIONS + a], (unsigned long long)q_pen);
-              else if (j < nb + nbd) {
-                const int b = j < nb ? S.best_actions[b0 + j] : S.bestd_actions[d0 + (j - nb)];
-                if (a != b) atomicAdd((unsigned long long*)&h[kStatsMain + y * EG_N_ACTIONS + a], (unsigned long long)q_mild);
-              }
-            }
-          }
-          const unsigned long long dmask = S.bestd_mask[y];
-          for (int j = 0; j < nd; ++j) {   // learning.rs:346-352
-            const int a = def[dp + j];
-            if (!((dmask >> a) & 1ull)) {
-              const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
-              if (slot >= 0) atomicAdd((unsigned long long*)&h[2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
-            }
-          }
-          rp += nr; dp += nd;
-        }
-      }
-    }
+// best episode of the batch: highest score, ties to the lowest index; its metrics and action lists are copied behind
+// the statistics so that one transfer carries everything the host-side update needs
+__global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsigned long long first_index, UpdateCandidate* cand) {
+  __shared__ double s_score[1024];
+  __shared__ int s_idx[1024];
+  const int tid = threadIdx.x;
+  double best = -1.0; int best_i = -1;
+  for (uint32_t i = tid; i < n; i += 1024) {
+    const double sc = O.score[i];
+    if (sc > best) { best = sc; best_i = (int)i; }      // ascending i per thread: first maximum
   }
+  s_score[tid] = best; s_idx[tid] = best_i;
   __syncthreads();
-  for (int i = threadIdx.x; i < kStatsBins; i += blockDim.x)
-    if (h[i] != 0) atomicAdd((unsigned long long*)&stats[8 + i], (unsigned long long)h[i]);
-  if (threadIdx.x < 3 && head[threadIdx.x] != 0) atomicAdd((unsigned long long*)&stats[threadIdx.x], (unsigned long long)head[threadIdx.x]);
+  for (int w = 512; w >= 1; w >>= 1) {
+    if (tid < w) {
+      const double o = s_score[tid + w]; const int oi = s_idx[tid + w];
+      if (oi >= 0 && (o > s_score[tid] || (o == s_score[tid] && (s_idx[tid] < 0 || oi < s_idx[tid])))) { s_score[tid] = o; s_idx[tid] = oi; }
+    }
+    __syncthreads();
+  }
+  const int win = s_idx[0];
+  if (tid == 0) { cand->score = win >= 0 ? s_score[0] : -1.0; cand->index = win >= 0 ? (long long)(first_index + (unsigned long long)win) : -1ll; }
+  if (win < 0) return;
+  if (tid < 4) cand->metrics[tid] = O.metrics[(size_t)win * 4 + tid];
+  if (tid < EG_YEARS) { cand->n_run[tid] = O.n_run[(size_t)win * EG_YEARS + tid]; cand->n_def[tid] = O.n_def[(size_t)win * EG_YEARS + tid]; }
+  for (int i = tid; i < EG_RUN_CAP; i += 1024) cand->run_log[i] = O.run_log[(size_t)win * EG_RUN_CAP + i];
+  for (int i = tid; i < EG_DEF_CAP; i += 1024) cand->def_log[i] = O.def_log[(size_t)win * EG_DEF_CAP + i];
 }
 
 }  // namespace
 
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, void* stream) {
+                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_rollout, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
-                     (unsigned long long)first_index, n, d_replay_mask);
+                     (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
@@ -791,7 +814,11 @@ int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_update_stats, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, o, s, p, n, d_stats);
+  hipLaunchKernelGGL(k_update_stats, dim3(n), dim3(kWave), 0, (hipStream_t)stream, o, s, p, n, d_stats);
+  return (int)hipGetLastError();
+}
+int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCandidate* d_cand, void* stream) {
+  hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(1024), 0, (hipStream_t)stream, o, n, (unsigned long long)first_index, d_cand);
   return (int)hipGetLastError();
 }
 

@@ -245,6 +245,15 @@ class Engine:
         N.check(N.lib().eg_rollout_launch(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index),
                                           n_episodes, mask), "eg_rollout_launch")
 
+    def launch_update(self, seed: int, first_episode_index: int, n_episodes: int, d_packet_ptr: int, replay_mask=None):
+        """Fused step: rollout + update statistics + best-candidate pick into a PACKET_BYTES device buffer."""
+        mask = None
+        if replay_mask is not None:
+            self._mask = np.ascontiguousarray(replay_mask, dtype=np.uint8)
+            mask = _p(self._mask, C.c_uint8)
+        N.check(N.lib().eg_rollout_launch_update(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index),
+                                                 n_episodes, mask, C.c_void_p(d_packet_ptr)), "eg_rollout_launch_update")
+
     def sync(self):
         N.check(N.lib().eg_sync(self.h), "eg_sync")
 

@@ -53,20 +53,48 @@ def unpack_candidate(buf: np.ndarray):
     return m, nr, rl, nd, dl
 
 
-CANDIDATE_BYTES = 32 + 8 * N.YEARS + N.RUN_CAP + N.DEF_CAP
+CANDIDATE_BYTES = 32 + 8 * N.YEARS + N.RUN_CAP + N.DEF_CAP   # payload without the (score, index) header
+
+
+def parse_candidate(buf: np.ndarray):
+    """Candidate record of the update packet (include/eirgrid_hip.h): returns (score, global index, candidate tuple)."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    score = float(buf[0:8].view(np.float64)[0]); index = int(buf[8:16].view(np.int64)[0])
+    return score, index, unpack_candidate(buf[16:])
+
+
+def exchange_packet(packet, dist=None):
+    """The whole per-update exchange on an update packet (torch uint8 tensor [PACKET_BYTES] on the device):
+    ONE sum all-reduce of the int64 statistics part + an all-gather of the per-rank candidate records (3.3 KB each).
+    Returns (stats ndarray, candidate tuple | None); every rank computes the same result."""
+    import torch
+    nstat = 8 * N.STATS_LEN
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        host = packet.cpu().numpy()
+        score, index, cand = parse_candidate(host[nstat:])
+        return host[:nstat].view(np.int64).copy(), (cand if index >= 0 else None)
+    ws = dist.get_world_size()
+    stats = packet[:nstat].view(torch.int64)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)                    # the one all-reduce of the update
+    cands = torch.empty(ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
+    dist.all_gather_into_tensor(cands, packet[nstat:].contiguous())
+    host_stats = stats.cpu().numpy().copy()
+    host_cands = cands.cpu().numpy().reshape(ws, N.CANDIDATE_BYTES)
+    parsed = [parse_candidate(host_cands[r]) for r in range(ws)]
+    win = pick_candidate([(p[0], p[1]) for p in parsed])
+    return host_stats, (parsed[win[0]][2] if win is not None else None)
 
 
 def exchange_update(stats, local_pair, local_payload_fn, dist=None, device=None):
-    """The whole per-update exchange.  `stats`: torch int64 tensor [STATS_LEN] (summed in place), `local_pair`:
-    (score, global index) of this rank's best episode (index -1 if none), `local_payload_fn()` → uint8 ndarray
-    [CANDIDATE_BYTES] of that episode (only called on the winning rank).  Returns (stats ndarray, candidate tuple|None).
-    With dist=None (single process) nothing is exchanged."""
+    """Exchange for callers that hold the pieces separately (used by the CPU/gloo tests): `stats` torch int64 tensor
+    [STATS_LEN] (summed in place), `local_pair` = (score, global index) of this rank's best episode (index -1 if none),
+    `local_payload_fn()` → uint8 ndarray [CANDIDATE_BYTES - 16] of that episode."""
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         cand = unpack_candidate(local_payload_fn()) if local_pair[1] >= 0 else None
         return stats.cpu().numpy(), cand
     ws, rank = dist.get_world_size(), dist.get_rank()
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM)                         # the one all-reduce of the update
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     pair = torch.tensor([float(local_pair[0]), float(local_pair[1])], dtype=torch.float64, device=device)
     gathered = [torch.empty_like(pair) for _ in range(ws)]
     dist.all_gather(gathered, pair)
@@ -93,7 +121,7 @@ class BatchTrainer:
         self.eng, self.w = engine, weights
         self.n, self.seed, self.rank, self.ws = episodes_per_rank, seed, rank, world_size
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.stats = torch.zeros(N.STATS_LEN, dtype=torch.int64, device=self.device)
+        self.packet = torch.zeros(N.PACKET_BYTES, dtype=torch.uint8, device=self.device)
         self.replay_fraction = replay_fraction
         self.write_yearly = write_yearly
         self.step_index = 0
@@ -108,17 +136,8 @@ class BatchTrainer:
             period = max(1, int(round(1.0 / self.replay_fraction)))
             mask = ((np.arange(first, first + self.n) % period) == 0).astype(np.uint8)
         self.eng.upload_snapshot(self.w, write_yearly=self.write_yearly)
-        self.eng.launch(self.seed, first, self.n, mask)
-        self.eng.update_stats(self.stats.data_ptr())
-        scores = self.eng.fetch_scores(self.n)                          # synchronises with the stream
-        ok = scores >= 0.0
-        if ok.any():
-            best_local = int(np.flatnonzero(scores == scores[ok].max())[0])
-            pair = (float(scores[best_local]), first + best_local)
-        else:
-            best_local, pair = -1, (-1.0, -1)
-        stats, cand = exchange_update(self.stats, pair, lambda: pack_candidate(*self.eng.fetch_episode_lists(best_local)),
-                                      self.dist, self.device)
+        self.eng.launch_update(self.seed, first, self.n, self.packet.data_ptr(), mask)   # rollout + stats + best pick
+        stats, cand = exchange_packet(self.packet, self.dist)                             # all-reduce + one D2H copy
         improved = apply_reduced(self.w, stats, cand, noise_seed=self.seed + self.step_index)
         self.improvements += int(improved)
         self.step_index += 1

@@ -164,6 +164,16 @@ int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
  *   [8 + 2*26*61 + y*15 + slot]  deficit actions absent from best_deficit_actions[y], learning.rs:346-352 */
 #define EG_STATS_LEN (8 + 2 * EG_YEARS * EG_N_ACTIONS + EG_YEARS * EG_N_DEFICIT)
 int32_t eg_update_stats(eg_ctx *, int64_t *d_stats);
+/* The timed path fuses all of it: one launch runs the batch, accumulates the statistics in the kernel's epilogue and
+ * picks the batch's best episode (highest score, ties to the lowest global index).  `d_packet` (DEVICE pointer,
+ * EG_PACKET_BYTES) = int64 stats[EG_STATS_LEN] followed by the candidate record:
+ *   f64 score (-1: none) | i64 global index | f64 metrics[4] | i32 n_run[26] | i32 n_def[26] | u8 run_log[EG_RUN_CAP] |
+ *   u8 def_log[EG_DEF_CAP]
+ * so that one device-to-host copy (after the all-reduce of the stats part when N > 1) feeds eg_policy_apply_reduced. */
+#define EG_CANDIDATE_BYTES (8 + 8 + 32 + 4 * EG_YEARS + 4 * EG_YEARS + EG_RUN_CAP + EG_DEF_CAP)
+#define EG_PACKET_BYTES (8 * EG_STATS_LEN + EG_CANDIDATE_BYTES)
+int32_t eg_rollout_launch_update(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes,
+                                 const uint8_t *replay_mask /* host, may be NULL */, void *d_packet);
 /* score_metrics of every episode of the last batch (written by eg_update_stats; -1 for failed episodes) */
 int32_t eg_fetch_scores(eg_ctx *, double *scores);
 /* metrics and action lists of one episode of the last batch (the best-candidate broadcast of SURVEY.md §8(e)) */

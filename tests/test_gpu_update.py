@@ -118,3 +118,25 @@ def test_trainer_steps_are_deterministic(engine):
         runs.append((flags, w.tobytes(), dw.tobytes(), pol.get("iteration_count"), pol.lists(0)))
     assert runs[0] == runs[1]
     assert runs[0][0][0] is True and runs[0][3] == 6 * 128
+
+
+def test_fused_packet_matches_separate_kernels(engine):
+    """eg_rollout_launch_update (statistics in the rollout epilogue + device-side best pick) == launch + eg_update_stats."""
+    from eirgrid_amd.parallel import exchange_packet
+    pol = _seed_best(engine)
+    n = 384
+    engine.upload_snapshot(pol)
+    packet = torch.zeros(N.PACKET_BYTES, dtype=torch.uint8, device="cuda")
+    engine.launch_update(31, 7000, n, packet.data_ptr())
+    stats_f, cand = exchange_packet(packet)
+    stats = torch.zeros(N.STATS_LEN, dtype=torch.int64, device="cuda")
+    engine.launch(31, 7000, n); engine.update_stats(stats.data_ptr())
+    scores = engine.fetch_scores(n)
+    assert (stats.cpu().numpy() == stats_f).all()
+    b = int(np.argmax(scores))          # first maximum = lowest index on ties
+    m, nr, rl, nd, dl = engine.fetch_episode_lists(b)
+    assert cand is not None
+    assert cand[0].tobytes() == m.tobytes() and (cand[1] == nr).all() and (cand[3] == nd).all()
+    assert cand[2][:nr.sum()].tobytes() == rl[:nr.sum()].tobytes() and cand[4][:nd.sum()].tobytes() == dl[:nd.sum()].tobytes()
+    host = packet.cpu().numpy()[8 * N.STATS_LEN:]
+    assert host[0:8].view(np.float64)[0] == scores[b] and host[8:16].view(np.int64)[0] == 7000 + b
