@@ -38,6 +38,22 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
+def pmc_traffic(episodes: int):
+    """HBM bytes per k_rollout launch from the newest committed PMC profile for this batch size (profiles/*pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, gfx950 correction applied) or None.
+    Counters cannot be collected from inside the process, so the number comes from the committed profile of the same build."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json"))):
+        try:
+            cfg = json.load(open(path))["configs"].get(str(episodes))
+        except (OSError, ValueError, KeyError):
+            continue
+        if cfg:
+            best = float(cfg["hbm_bytes_per_launch"])
+    return best
+
+
 def cpu_baseline(world, seconds_budget: float = 20.0):
     """The CPU oracle (C restatement of the reference algorithm — NOT the Rust/rayon binary, which cannot be built here)
     timed on this box's host cores: literal mode (same work as the reference: 100x100 candidate search with sqrt+div per
@@ -155,7 +171,7 @@ def main():
                        "parallelism": f"episode-sharded dp{world_size}, one int64 stats all-reduce per update",
                        "episodes_ok_last_batch": ok, "strategy_improvements": trainer.improvements},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_rollout",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.episodes), "kernel": "k_rollout",
                          "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_episode": bytes_per_launch / max(args.episodes, 1),
                          "kernel_only_episodes_per_s": args.episodes / avg_kernel_s if avg_kernel_s > 0 else 0.0},
