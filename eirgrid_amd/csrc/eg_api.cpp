@@ -74,7 +74,8 @@ namespace {
 constexpr size_t kSnapW = 0;
 constexpr size_t kSnapDw = kSnapW + sizeof(double) * EG_YEARS * EG_N_ACTIONS;
 constexpr size_t kSnapCw = kSnapDw + sizeof(double) * EG_YEARS * EG_N_DEFICIT;
-constexpr size_t kSnapMask = kSnapCw + sizeof(double) * EG_YEARS * EG_N_COUNTS;
+constexpr size_t kSnapTotals = kSnapCw + sizeof(double) * EG_YEARS * EG_N_COUNTS;
+constexpr size_t kSnapMask = kSnapTotals + sizeof(double) * EG_YEARS * 3;
 constexpr size_t kSnapDmask = kSnapMask + 8 * EG_YEARS;
 constexpr size_t kSnapOff = kSnapDmask + 8 * EG_YEARS;
 constexpr size_t kSnapOffd = kSnapOff + 4 * 28;
@@ -266,6 +267,17 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   std::memcpy(h + kSnapW, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
   std::memcpy(h + kSnapDw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT);
   if (s->count_weights) std::memcpy(h + kSnapCw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS);
+  {  // sampling.rs:182, :352-355, :406: the sums the samplers start from, folded in table order like the device does
+    double tot[EG_YEARS * 3];
+    for (int y = 0; y < EG_YEARS; ++y) {
+      double a = 0.0, b = 0.0, c2 = 0.0;
+      for (int i = 0; i < EG_N_ACTIONS; ++i) a += s->weights[y * EG_N_ACTIONS + i];
+      for (int i = 0; i < 14; ++i) b += s->deficit_weights[y * EG_N_DEFICIT + i];
+      if (s->count_weights) for (int i = 0; i < EG_N_COUNTS; ++i) c2 += s->count_weights[y * EG_N_COUNTS + i];
+      tot[3 * y] = a; tot[3 * y + 1] = b; tot[3 * y + 2] = c2;
+    }
+    std::memcpy(h + kSnapTotals, tot, sizeof(tot));
+  }
   unsigned long long mask[26] = {0}, dmask[26] = {0};
   if (have_lists)
     for (int y = 0; y < EG_YEARS; ++y) {
@@ -280,6 +292,7 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   S = DevSnapshot{};
   S.w = reinterpret_cast<const double*>(c->d_snap + kSnapW); S.dw = reinterpret_cast<const double*>(c->d_snap + kSnapDw);
   S.cw = s->count_weights ? reinterpret_cast<const double*>(c->d_snap + kSnapCw) : nullptr;
+  S.row_totals = reinterpret_cast<const double*>(c->d_snap + kSnapTotals);
   S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
   S.has_best = s->has_best ? 1 : 0;
   // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)

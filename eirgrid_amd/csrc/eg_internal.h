@@ -78,6 +78,7 @@ struct DevSnapshot {
   const double* w;    // [26][61]
   const double* dw;   // [26][15]
   const double* cw;   // [26][21] or nullptr
+  const double* row_totals;   // [26][3] table-order sums of the w / dw (first 14) / cw rows of each year (host-evaluated)
   double learning_rate, exploration_rate;
   uint32_t stall;
   int32_t has_best;

@@ -40,6 +40,10 @@ __constant__ int c_deficit_slot[15] = {5, 6, 10, 11, 7, 9, -1, 1, 0, 4, 8, 3, 2,
 struct __align__(16) Smem {
   double dr[kRadiusClasses * 169];    // d/R by (|di|, |dj|) for every radius class; 1.0 where d >= R
   double scaled[64];                  // stalled sampler: weights^p in sorted order
+  double type_out[16];                // per generator type: output of an operational new plant
+  double type_co2[16];                //                     CO2
+  int type_info[16];                  //                     variant | radius class << 4 | reach << 8 | output class << 12
+  double acc[8];                      // once-a-year accumulators kept out of registers: total cost / credit / sales, last row
   double w[64];                       // this year's main weights (61 used)
   double dw[16];                      // this year's deficit weights (15 used)
   double cw[24];                      // this year's action-count weights (21 used)
@@ -60,6 +64,10 @@ __shared__ Smem sm;
 struct Rng {      // register part of the stream state; key / counter / buffer live in LDS
   int index;
   unsigned int words;
+};
+struct Totals {   // sums of the weight rows in table order (sampling.rs:182, :352-355); recomputed only after a nudge
+  double main, deficit;
+  bool main_valid, deficit_valid;
 };
 
 struct Agg {   // aggregates of the map at the current point of the year (map_handler.rs:819-965)
@@ -178,6 +186,17 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
   return cost_improvement * cost_weight + opinion_improvement * opinion_weight;
 }
 
+// small per-type / per-class tables -> LDS (one dependent LDS read instead of chains of L2 round trips)
+__device__ __forceinline__ void load_static_tables(const DevTables& T, int lane) {
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
+  if (lane < kTypes) {
+    const int rc = T.rclass[lane];
+    sm.type_info[lane] = T.variant[lane] | (rc << 4) | (T.reach[rc] << 8) | (T.cls[lane] << 12);
+    sm.type_out[lane] = T.out_mw[lane];
+    sm.type_co2[lane] = T.co2_t[lane];
+  }
+}
+
 // ---- placement: arg-max over the 51x51 distinct candidates (Q10) -------------------------------------------
 // Reference (metal_location_search.rs:110-176): score(c) = ((te[c] * prod_{g in list order, d<R} d/R) * coast(c)) * 0.9,
 // keep the first strictly greater score in (i, j) order, i.e. the maximum with ties to the lowest cell index.
@@ -190,10 +209,10 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-__device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score) {
-  const int v = T.variant[type];
-  const int rc = T.rclass[type];
-  const int reach = T.reach[rc];
+__device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
+                                            unsigned long long* stamps = nullptr) {
+  const int info = sm.type_info[type];
+  const int v = info & 15, rc = (info >> 4) & 15;
   const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
   const uint16_t* __restrict__ cells = T.ps_cell + o;
   const double* __restrict__ tes = T.ps_te + o;
@@ -201,42 +220,73 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   const double* dr = sm.dr + rc * 169;
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
+  constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double best = 0.0; int best_c = kCells;
-  for (int chunk = 0; chunk < (kCells + kWave - 1) / kWave; ++chunk) {
+  // chunk 0 is loaded here, chunk k+1 while chunk k is being evaluated
+  double te = tes[lane], cf = cfs[lane]; int cell = cells[lane];
+  for (int chunk = 0; chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
-    const double te = tes[r];                 // padded with 0.0 beyond the 2601 candidates
-    const double cf = cfs[r];
-    const int cell = cells[r];
-    const double base = (te * cf) * size_factor;
+    const double base = (te * cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
     if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
-    const int ci = cell / kGrid, cj = cell - ci * kGrid;
-    double s = te;
+    const double te_cur = te, cf_cur = cf; const int cell_cur = cell;
+    if (chunk + 1 < kChunks) { te = tes[r + kWave]; cf = cfs[r + kWave]; cell = cells[r + kWave]; }
+#ifdef EG_STAMPS
+    if (stamps) stamps[8] += 1;
+    const unsigned long long tg0 = __builtin_readcyclecounter();
+#endif
+    const int ci = cell_cur / kGrid, cj = cell_cur - ci * kGrid;
+    double s = te_cur;
     for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
       const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : 0;
+      const int mi = mine / kGrid;
+      const int mp = mi | ((mine - mi * kGrid) << 8);                // (gi, gj) packed: one readlane per generator
       const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-      for (int j = 0; j < cnt; ++j) {
-        const int gc = __builtin_amdgcn_readlane(mine, j);
-        const int gi = gc / kGrid, gj = gc - gi * kGrid;
-        int di = ci - gi, dj = cj - gj;
+      // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
+      // exactly, so out-of-range generators multiply by 1.0 instead of branching.  Four generators per trip: the
+      // index arithmetic and LDS reads of the four are independent, only the four multiplies are a chain.
+      int j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        double f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = __builtin_amdgcn_readlane(mp, j + u);
+          int di = ci - (p & 0xFF), dj = cj - (p >> 8);
+          di = di < 0 ? -di : di; dj = dj < 0 ? -dj : dj;
+          di = di > 12 ? 12 : di; dj = dj > 12 ? 12 : dj;
+          f[u] = dr[di * 13 + dj];
+        }
+        s = s * f[0]; s = s * f[1]; s = s * f[2]; s = s * f[3];
+      }
+      for (; j < cnt; ++j) {
+        const int p = __builtin_amdgcn_readlane(mp, j);
+        int di = ci - (p & 0xFF), dj = cj - (p >> 8);
         di = di < 0 ? -di : di; dj = dj < 0 ? -dj : dj;
-        if (di <= reach && dj <= reach) s = s * dr[di * 13 + dj];
+        di = di > 12 ? 12 : di; dj = dj > 12 ? 12 : dj;
+        s = s * dr[di * 13 + dj];
       }
     }
-    s = (s * cf) * size_factor;
+#ifdef EG_STAMPS
+    const unsigned long long tg1 = __builtin_readcyclecounter();
+    if (stamps) stamps[9] += tg1 - tg0;
+#endif
+    s = (s * cf_cur) * size_factor;
     if (r >= kCells) s = 0.0;
-    if (__any(s > best || (s == best && s > 0.0 && cell < best_c))) {
+    if (__any(s > best || (s == best && s > 0.0 && cell_cur < best_c))) {
       double wmax = s;
 #pragma unroll
       for (int sh = 32; sh >= 1; sh >>= 1) { const double other = __shfl_xor(wmax, sh); wmax = other > wmax ? other : wmax; }
-      int win_c = s == wmax ? cell : kCells;
+      int win_c = s == wmax ? cell_cur : kCells;
       const unsigned long long holders = __ballot(s == wmax);
-      if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell, __ffsll((long long)holders) - 1);
+      if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell_cur, __ffsll((long long)holders) - 1);
       else {
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) { const int other = __shfl_xor(win_c, sh); win_c = other < win_c ? other : win_c; }
       }
       if (wmax > best || (wmax == best && win_c < best_c)) { best = wmax; best_c = win_c; }
     }
+#ifdef EG_STAMPS
+    if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
+#endif
   }
   if (best_score) *best_score = best;
   return best > 0.0 ? best_c : -1;
@@ -301,13 +351,17 @@ __device__ int smart_deficit_fallback(Rng& r, int lane) {   // sampling.rs:492-5
   if (choice < 3u) return 12;
   return 3 * kBattery;
 }
-__device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, int lane) {   // sampling.rs:147-237
+__device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:147-237
   const double eps = S.stall > 100u ? S.exploration_rate * (1.0 / (1.0 + 0.01 * (double)S.stall)) : S.exploration_rate;
   const bool explore = rng_f64(r, lane) < eps;
   if (explore) return (int)rng_range64(r, lane, (unsigned long long)EG_N_ACTIONS);
-  double total = 0.0;
+  if (!tot.main_valid) {
+    double t = 0.0;
 #pragma unroll 4
-  for (int a = 0; a < EG_N_ACTIONS; ++a) total += sm.w[a];
+    for (int a = 0; a < EG_N_ACTIONS; ++a) t += sm.w[a];
+    tot.main = t; tot.main_valid = true;
+  }
+  const double total = tot.main;
   if (total <= 0.0) return 3 * kPeaker;
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
     const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
@@ -333,21 +387,32 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, int lane) { 
     return pick;
   }
   double v = rng_f64(r, lane) * total;
-#pragma unroll 4
-  for (int a = 0; a < EG_N_ACTIONS; ++a) { v -= sm.w[a]; if (v <= 0.0) return a; }
-  return 3 * kPeaker;
+  int pick = -1;                      // eight entries per trip, branch-free inside: the LDS reads pipeline
+  for (int a0 = 0; a0 < EG_N_ACTIONS && pick < 0; a0 += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int a = a0 + u;
+      if (a < EG_N_ACTIONS) { v -= sm.w[a]; pick = (pick < 0 && v <= 0.0) ? a : pick; }
+    }
+  }
+  return pick >= 0 ? pick : 3 * kPeaker;
 }
-__device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, int lane) {   // sampling.rs:315-377
+__device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:315-377
   const bool explore = rng_f64(r, lane) < S.exploration_rate;
   if (explore) return 3 * c_deficit_type[(int)rng_range64(r, lane, 14ull)];
-  double total = 0.0;
-#pragma unroll 2
-  for (int i = 0; i < 14; ++i) total += sm.dw[i];
+  if (!tot.deficit_valid) {
+    double t = 0.0;
+#pragma unroll 7
+    for (int i = 0; i < 14; ++i) t += sm.dw[i];
+    tot.deficit = t; tot.deficit_valid = true;
+  }
+  const double total = tot.deficit;
   if (total <= 0.0) return 3 * kPeaker;
   double v = rng_f64(r, lane) * total;
-#pragma unroll 2
-  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; if (v <= 0.0) return 3 * c_deficit_type[i]; }
-  return 3 * kPeaker;
+  int pick = -1;
+#pragma unroll 7
+  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; pick = (pick < 0 && v <= 0.0) ? i : pick; }
+  return pick >= 0 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
 }
 
 struct Episode {   // wave-uniform bookkeeping of one episode
@@ -439,11 +504,11 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
   const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
-  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
 
-  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
+  load_static_tables(T, lane);
   Rng rng;
   rng_seed(rng, seed + first_index + (unsigned long long)e, lane);   // simulation.rs:50-53, one stream per episode
 
@@ -458,18 +523,22 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
 
   double gcost_end = 0.0, ocost_end = 0.0;                 // last year's end-of-year capital sums
   double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
-  double total_cost = 0.0, total_credit = 0.0, total_sales = 0.0;   // accumulators of metrics_calculation.rs:133-153
-  double last_net = 0.0, last_opinion = 0.0, last_capital = 0.0, last_balance = 0.0;
+  if (lane < 8) sm.acc[lane] = 0.0;   // [0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row
 
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
-    // this year's policy rows -> LDS
+    {  // this year's policy rows -> LDS
+    EG_T0();
     __syncthreads();
     if (lane < EG_N_ACTIONS) sm.w[lane] = S.w[yi * EG_N_ACTIONS + lane];
     if (lane < EG_N_DEFICIT) sm.dw[lane] = S.dw[yi * EG_N_DEFICIT + lane];
     if (S.cw != nullptr && lane < EG_N_COUNTS) sm.cw[lane] = S.cw[yi * EG_N_COUNTS + lane];
     __syncthreads();
+    EG_T1(5);
+    }
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
+    Totals tot; tot.main = S.row_totals[3 * yi]; tot.deficit = S.row_totals[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
+    const double cw_total = S.row_totals[3 * yi + 2];
 
     // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
     //      The lanes gather the per-generator terms in parallel; the sums are then folded lane by lane (readlane),
@@ -497,12 +566,20 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         const double2 cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t * kYears + b) * kMults + m) * 2);
         const double op = (T.m03[cell] + t12y[t]) + cc.y;
         double out = 0.0, co2 = 0.0; int cls = 0;
-        if (!carry) { out = T.out_mw[t]; co2 = T.co2_t[t]; cls = T.cls[t]; }
+        if (!carry) { out = sm.type_out[t]; co2 = sm.type_co2[t]; cls = (sm.type_info[t] >> 12) & 3; }
         const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
-        for (int j = 0; j < cnt; ++j) {
-          a.gcost += readlane_f64(cc.x, j);
-          a.optot += readlane_f64(op, j);
-          if (!carry) {
+        if (carry) {            // the common year: two independent chains, four generators per trip
+          int j = 0;
+          for (; j + 4 <= cnt; j += 4) {
+            const double c0 = readlane_f64(cc.x, j), c1 = readlane_f64(cc.x, j + 1), c2 = readlane_f64(cc.x, j + 2), c3 = readlane_f64(cc.x, j + 3);
+            const double o0 = readlane_f64(op, j), o1 = readlane_f64(op, j + 1), o2 = readlane_f64(op, j + 2), o3 = readlane_f64(op, j + 3);
+            a.gcost += c0; a.optot += o0; a.gcost += c1; a.optot += o1; a.gcost += c2; a.optot += o2; a.gcost += c3; a.optot += o3;
+          }
+          for (; j < cnt; ++j) { a.gcost += readlane_f64(cc.x, j); a.optot += readlane_f64(op, j); }
+        } else {
+          for (int j = 0; j < cnt; ++j) {
+            a.gcost += readlane_f64(cc.x, j);
+            a.optot += readlane_f64(op, j);
             const double oj = readlane_f64(out, j);
             const int cj = __builtin_amdgcn_readlane(cls, j);
             a.co2 += readlane_f64(co2, j);
@@ -547,6 +624,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
             const double factor = 0.1 * success;
             __syncthreads();
             for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, lane, sm.ydef[i], factor);
+            tot.deficit_valid = false;
           }
           phase = 1;
           continue;
@@ -561,7 +639,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
             if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; break; }
             if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
             ep.def_pos += 1; ep.n_def_y += 1;
-          } else action = sample_deficit_weighted(S, rng, lane);
+          } else action = sample_deficit_weighted(S, rng, tot, lane);
         } else action = 3 * kBattery;   // simulation.rs:369-376
         EG_T1(2);
         if (action >= kFirstOffset) continue;   // only AddGenerator actions are applied in the repair loop (:398)
@@ -579,9 +657,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
               const double u = rng_f64(rng, lane);
               if (S.cw != nullptr) {
                 const double* cw = sm.cw;
-                double total = 0.0;
-#pragma unroll 3
-                for (int c = 0; c < EG_N_COUNTS; ++c) total += cw[c];
+                const double total = cw_total;   // the count table is never nudged (Q3): its sum is a snapshot constant
                 if (total > 0.0) {
                   double v = u * total;
                   n_add = 5u < cap ? 5u : cap;
@@ -607,7 +683,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
           if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
           if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
           ep.run_pos += 1; ep.n_run_y += 1;
-        } else action = sample_action_weighted(S, rng, lane);
+        } else action = sample_action_weighted(S, rng, tot, lane);
         EG_T1(2);
       }
 
@@ -615,11 +691,21 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
       if (action < kFirstOffset) {
         const int t = action / 3, m = action - 3 * t;
         ep.bytes += (double)kCells * 8.0 + (double)(n_existing + ep.ngen) * 16.0;
+        // terms that depend only on (year, type, multiplier) are requested before the search and land while it runs
+        const double2 ccv = *reinterpret_cast<const double2*>(T.cc + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
+        const double cc_prev = yi > 0 ? T.cc[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
+        const double t12v = T.t12[(size_t)yi * kTypes + t];
         EG_T0();
+#ifdef EG_STAMPS
+        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, stamps);
+        stamps[11] += 1;
+#else
         const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr);
+#endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
+        const double m03v = T.m03[cell];
         if (lane == 0) {
           sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
           sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
@@ -628,14 +714,13 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         }
         __syncthreads();
         ep.ngen += 1;
-        const double* cc = T.cc + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2;
-        a.gcost += cc[0];
-        if (yi > 0) a.gcost_prev += T.cc[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2];
-        a.co2 += T.co2_t[t];
-        const double out = T.out_mw[t];
-        const int cls = T.cls[t];
+        a.gcost += ccv.x;
+        if (yi > 0) a.gcost_prev += cc_prev;
+        a.co2 += sm.type_co2[t];
+        const double out = sm.type_out[t];
+        const int cls = (sm.type_info[t] >> 12) & 3;
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
-        a.optot += (T.m03[cell] + T.t12[(size_t)yi * kTypes + t]) + cc[1];
+        a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
       } else if (action < kFirstOther) {
         const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
@@ -664,6 +749,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
         update_deficit_weights(S, lane, action, combined);
         update_weights(S, lane, action, overall * 0.5);
+        tot.main_valid = false; tot.deficit_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
         EG_T1(3);
       } else {            // simulation.rs:193-197
@@ -685,34 +771,24 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     double sales = 0.0;
     if (S.enable_energy_sales && s.balance > 0.0) { const double gwh = s.balance * 8.76; sales = gwh * 50000.0; }
     const double yearly_total = yearly_capital + 0.0 + 0.0 - credit - (S.enable_energy_sales ? sales : 0.0);
-    total_cost = yi == 0 ? yearly_total : total_cost + yearly_total;
-    total_credit = yi == 0 ? credit : total_credit + credit;
-    total_sales = yi == 0 ? sales : total_sales + sales;
-    if (S.write_yearly && O.yearly != nullptr) {
-      double v = 0.0;
-      switch (lane) {
-        case EG_Y_YEAR: v = (double)year; break;
-        case EG_Y_POP: v = T.population[yi]; break;
-        case EG_Y_USAGE: v = a.usage; break;
-        case EG_Y_GEN: v = gen; break;
-        case EG_Y_BALANCE: v = s.balance; break;
-        case EG_Y_OPINION: v = s.opinion; break;
-        case EG_Y_YEARLY_CAPITAL: v = yearly_capital; break;
-        case EG_Y_TOTAL_CAPITAL: v = total_capital; break;
-        case EG_Y_INFLATION: v = T.inflation[yi]; break;
-        case EG_Y_CO2: v = a.co2; break;
-        case EG_Y_OFFSET: v = a.offs; break;
-        case EG_Y_NET_CO2: v = s.net; break;
-        case EG_Y_YEARLY_CREDIT: v = credit; break;
-        case EG_Y_TOTAL_CREDIT: v = total_credit; break;
-        case EG_Y_YEARLY_SALES: v = sales; break;
-        case EG_Y_TOTAL_SALES: v = total_sales; break;
-        case EG_Y_ACTIVE_GENS: v = (double)a.opcnt; break;
-        case EG_Y_YEARLY_TOTAL_COST: v = yearly_total; break;
-        case EG_Y_TOTAL_COST: v = total_cost; break;
-        default: v = 0.0; break;   // upgrade / closure costs are identically 0 (simulation.rs:41-42)
-      }
-      if (lane < EG_YEARLY_FIELDS) O.yearly[((size_t)e * kYears + yi) * EG_YEARLY_FIELDS + lane] = v;
+    __syncthreads();
+    const double total_cost = yi == 0 ? yearly_total : sm.acc[0] + yearly_total;
+    const double total_credit = yi == 0 ? credit : sm.acc[1] + credit;
+    const double total_sales = yi == 0 ? sales : sm.acc[2] + sales;
+    __syncthreads();
+    if (lane == 0) {
+      sm.acc[0] = total_cost; sm.acc[1] = total_credit; sm.acc[2] = total_sales;
+      sm.acc[3] = s.net; sm.acc[4] = s.opinion; sm.acc[5] = total_capital; sm.acc[6] = s.balance;
+    }
+    if (S.write_yearly && O.yearly != nullptr && lane == 0) {   // one lane: 21 adjacent 8-byte stores (merged pairwise)
+      double* row = O.yearly + ((size_t)e * kYears + yi) * EG_YEARLY_FIELDS;
+      row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = T.population[yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
+      row[EG_Y_BALANCE] = s.balance; row[EG_Y_OPINION] = s.opinion; row[EG_Y_YEARLY_CAPITAL] = yearly_capital;
+      row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = T.inflation[yi]; row[EG_Y_CO2] = a.co2;
+      row[EG_Y_OFFSET] = a.offs; row[EG_Y_NET_CO2] = s.net; row[EG_Y_YEARLY_CREDIT] = credit; row[EG_Y_TOTAL_CREDIT] = total_credit;
+      row[EG_Y_YEARLY_SALES] = sales; row[EG_Y_TOTAL_SALES] = total_sales; row[EG_Y_ACTIVE_GENS] = (double)a.opcnt;
+      row[EG_Y_UPGRADE_COSTS] = 0.0; row[EG_Y_CLOSURE_COSTS] = 0.0;   // identically 0 (simulation.rs:41-42)
+      row[EG_Y_YEARLY_TOTAL_COST] = yearly_total; row[EG_Y_TOTAL_COST] = total_cost;
     }
     if (lane == 0) {
       O.n_run[(size_t)e * kYears + yi] = ep.n_run_y;
@@ -721,15 +797,15 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     }
     gcost_end = a.gcost; ocost_end = a.ocost;
     co2_end = a.co2; tg_end = a.tg; ig_end = a.ig; sg_end = a.sg;
-    last_net = s.net; last_opinion = s.opinion; last_capital = total_capital; last_balance = s.balance;
     EG_T1(4);
   }
 
+  __syncthreads();
   if (lane == 0) {   // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
-    O.metrics[(size_t)e * 4 + 0] = last_net;
-    O.metrics[(size_t)e * 4 + 1] = last_opinion;
-    O.metrics[(size_t)e * 4 + 2] = last_capital;
-    O.metrics[(size_t)e * 4 + 3] = last_balance >= 0.0 ? 1.0 : 0.0;
+    O.metrics[(size_t)e * 4 + 0] = sm.acc[3];
+    O.metrics[(size_t)e * 4 + 1] = sm.acc[4];
+    O.metrics[(size_t)e * 4 + 2] = sm.acc[5];
+    O.metrics[(size_t)e * 4 + 3] = sm.acc[6] >= 0.0 ? 1.0 : 0.0;
     O.status[e] = ep.status;
     O.n_gens[e] = ep.ngen;
     O.n_offsets[e] = ep.noff;
@@ -738,8 +814,8 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
 #ifdef EG_STAMPS
     stamps[7] = __builtin_readcyclecounter() - t_begin;
     // diagnostic build only: cycle shares go to the (otherwise unread) tail of this episode's act_log buffer
-    unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 64);
-    for (int i = 0; i < 8; ++i) dbg[i] = stamps[i];
+    unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 128);
+    for (int i = 0; i < 16; ++i) dbg[i] = stamps[i];
 #endif
   }
   if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes
@@ -754,7 +830,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
                                                  int n_extra, int32_t* out_cell, double* out_score) {
   const int lane = threadIdx.x;
   for (int g = lane; g < n_extra; g += kWave) sm.gcell[g] = cells[g];
-  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
+  load_static_tables(T, lane);
   __syncthreads();
   double score = 0.0;
   const int cell = place_search(T, lane, yi, type, n_extra, &score);
