@@ -10,7 +10,7 @@ import os
 
 YEARS, N_ACTIONS, N_DEFICIT, N_COUNTS, N_TYPES = 26, 61, 15, 21, 15
 GRID, CELLS, YEARLY_FIELDS = 51, 2601, 21
-MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 1024, 1024, 2048, 1024, 1024
+MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 512, 512, 2048, 1024, 1024
 STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
 CANDIDATE_BYTES = 8 + 8 + 32 + 4 * YEARS + 4 * YEARS + RUN_CAP + DEF_CAP
 PACKET_BYTES = 8 * STATS_LEN + CANDIDATE_BYTES

@@ -186,6 +186,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     const int NV = int(variants.size());
     std::vector<uint16_t> ps_cell(size_t(kYears) * NV * kPsStride, 0);
     std::vector<double> ps_te(size_t(kYears) * NV * kPsStride, 0.0), ps_cf(size_t(kYears) * NV * kPsStride, 1.0);
+    std::vector<double> ps_m03(size_t(kYears) * NV * kPsStride, 0.0);
     std::vector<double> base(kCells);
     std::vector<int> order(kCells);
     for (int y = 0; y < kYears; ++y)
@@ -197,9 +198,10 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         const size_t o = (size_t(y) * NV + v) * kPsStride;
         for (int r = 0; r < kCells; ++r) {
           ps_cell[o + r] = uint16_t(order[r]); ps_te[o + r] = te[order[r]]; ps_cf[o + r] = marine ? H.coastf[order[r]] : 1.0;
+          ps_m03[o + r] = H.m03[order[r]];
         }
       }
-    up(ps_cell, &D.ps_cell); up(ps_te, &D.ps_te); up(ps_cf, &D.ps_cf); up(variant_of, &D.variant);
+    up(ps_cell, &D.ps_cell); up(ps_te, &D.ps_te); up(ps_cf, &D.ps_cf); up(ps_m03, &D.ps_m03); up(variant_of, &D.variant);
     D.n_variants = NV;
   }
   up(H.dr, &D.dr);

@@ -61,7 +61,7 @@ struct DevTables {
   const double* pre_co2; const double* pre_tg; const double* pre_ig; const double* pre_sg; const double* pre_optot;
   const int32_t* pre_opcnt;
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  const uint16_t* ps_cell; const double* ps_te; const double* ps_cf;   // [26][n_variants][kPsStride]
+  const uint16_t* ps_cell; const double* ps_te; const double* ps_cf; const double* ps_m03;   // [26][n_variants][kPsStride]
   const int32_t* variant;   // [15] type -> variant
   int32_t n_variants;
   const double* dr; double size_factor;

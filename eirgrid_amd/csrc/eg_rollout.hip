@@ -44,6 +44,9 @@ struct __align__(16) Smem {
   double type_co2[16];                //                     CO2
   int type_info[16];                  //                     variant | radius class << 4 | reach << 8 | output class << 12
   double acc[8];                      // once-a-year accumulators kept out of registers: total cost / credit / sales, last row
+  double yr[9][EG_YEARS];             // per-year scalars: pre_co2, pre_tg, pre_ig, pre_sg, pre_optot, usage, population,
+                                      // inflation, carbon_price
+  int yr_opcnt[EG_YEARS];
   double w[64];                       // this year's main weights (61 used)
   double dw[16];                      // this year's deficit weights (15 used)
   double cw[24];                      // this year's action-count weights (21 used)
@@ -195,6 +198,11 @@ __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane)
     sm.type_out[lane] = T.out_mw[lane];
     sm.type_co2[lane] = T.co2_t[lane];
   }
+  if (lane < EG_YEARS) {
+    sm.yr[0][lane] = T.pre_co2[lane]; sm.yr[1][lane] = T.pre_tg[lane]; sm.yr[2][lane] = T.pre_ig[lane]; sm.yr[3][lane] = T.pre_sg[lane];
+    sm.yr[4][lane] = T.pre_optot[lane]; sm.yr[5][lane] = T.usage[lane]; sm.yr[6][lane] = T.population[lane];
+    sm.yr[7][lane] = T.inflation[lane]; sm.yr[8][lane] = T.carbon_price[lane]; sm.yr_opcnt[lane] = T.pre_opcnt[lane];
+  }
 }
 
 // ---- placement: arg-max over the 51x51 distinct candidates (Q10) -------------------------------------------
@@ -210,26 +218,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
-                                            unsigned long long* stamps = nullptr) {
+                                            double* best_m03, unsigned long long* stamps = nullptr) {
   const int info = sm.type_info[type];
   const int v = info & 15, rc = (info >> 4) & 15;
   const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
   const uint16_t* __restrict__ cells = T.ps_cell + o;
   const double* __restrict__ tes = T.ps_te + o;
   const double* __restrict__ cfs = T.ps_cf + o;
+  const double* __restrict__ m03s = T.ps_m03 + o;
   const double* dr = sm.dr + rc * 169;
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
-  double best = 0.0; int best_c = kCells;
+  double best = 0.0, m03w = 0.0; int best_c = kCells;
   // chunk 0 is loaded here, chunk k+1 while chunk k is being evaluated
-  double te = tes[lane], cf = cfs[lane]; int cell = cells[lane];
+  double te = tes[lane], cf = cfs[lane], m03 = m03s[lane]; int cell = cells[lane];
   for (int chunk = 0; chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
     const double base = (te * cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
     if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
-    const double te_cur = te, cf_cur = cf; const int cell_cur = cell;
-    if (chunk + 1 < kChunks) { te = tes[r + kWave]; cf = cfs[r + kWave]; cell = cells[r + kWave]; }
+    const double te_cur = te, cf_cur = cf, m03_cur = m03; const int cell_cur = cell;
+    if (chunk + 1 < kChunks) { te = tes[r + kWave]; cf = cfs[r + kWave]; m03 = m03s[r + kWave]; cell = cells[r + kWave]; }
 #ifdef EG_STAMPS
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
@@ -282,13 +291,18 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) { const int other = __shfl_xor(win_c, sh); win_c = other < win_c ? other : win_c; }
       }
-      if (wmax > best || (wmax == best && win_c < best_c)) { best = wmax; best_c = win_c; }
+      if (wmax > best || (wmax == best && win_c < best_c)) {
+        best = wmax; best_c = win_c;
+        const unsigned long long owner = __ballot(s == wmax && cell_cur == win_c);   // the lane that holds the winner
+        m03w = readlane_f64(m03_cur, __ffsll((long long)owner) - 1);
+      }
     }
 #ifdef EG_STAMPS
     if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
 #endif
   }
   if (best_score) *best_score = best;
+  if (best_m03) *best_m03 = m03w;
   return best > 0.0 ? best_c : -1;
 }
 
@@ -495,7 +509,7 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 #define EG_T1(slot) do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
+__global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
                                                    unsigned long long first_index, uint32_t n_episodes,
                                                    const uint8_t* __restrict__ replay_mask, StatsParams P, long long* stats) {
   const int lane = threadIdx.x;
@@ -525,14 +539,21 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
   double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
   if (lane < 8) sm.acc[lane] = 0.0;   // [0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row
 
+  double nw = lane < EG_N_ACTIONS ? S.w[lane] : 0.0, ndw = lane < EG_N_DEFICIT ? S.dw[lane] : 0.0;
+  double ncw = (S.cw != nullptr && lane < EG_N_COUNTS) ? S.cw[lane] : 0.0;
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
-    {  // this year's policy rows -> LDS
+    {  // this year's policy rows -> LDS (they were requested a year ahead: nw / ndw / ncw), then request next year's
     EG_T0();
     __syncthreads();
-    if (lane < EG_N_ACTIONS) sm.w[lane] = S.w[yi * EG_N_ACTIONS + lane];
-    if (lane < EG_N_DEFICIT) sm.dw[lane] = S.dw[yi * EG_N_DEFICIT + lane];
-    if (S.cw != nullptr && lane < EG_N_COUNTS) sm.cw[lane] = S.cw[yi * EG_N_COUNTS + lane];
+    if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
+    if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
+    if (lane < EG_N_COUNTS) sm.cw[lane] = ncw;
+    if (yi + 1 < kYears) {
+      if (lane < EG_N_ACTIONS) nw = S.w[(yi + 1) * EG_N_ACTIONS + lane];
+      if (lane < EG_N_DEFICIT) ndw = S.dw[(yi + 1) * EG_N_DEFICIT + lane];
+      if (S.cw != nullptr && lane < EG_N_COUNTS) ncw = S.cw[(yi + 1) * EG_N_COUNTS + lane];
+    }
     __syncthreads();
     EG_T1(5);
     }
@@ -545,14 +566,14 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     //      i.e. in list order.  Output / CO2 terms of a plant never change (delays off), so those three sums carry
     //      over from the end of last year whenever the existing-plant prefix did, bit for bit. ----
     Agg a;
-    a.usage = T.usage[yi];
+    a.usage = sm.yr[5][yi];
     a.gcost = 0.0; a.ocost = 0.0; a.offs = 0.0;
     a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
-    a.optot = T.pre_optot[yi]; a.opcnt = T.pre_opcnt[yi];
+    a.optot = sm.yr[4][yi]; a.opcnt = sm.yr_opcnt[yi];
     {
       EG_T0();
-      const double pco2 = T.pre_co2[yi], ptg = T.pre_tg[yi], pig = T.pre_ig[yi], psg = T.pre_sg[yi];
-      const bool carry = yi > 0 && pco2 == T.pre_co2[yi - 1] && ptg == T.pre_tg[yi - 1] && pig == T.pre_ig[yi - 1] && psg == T.pre_sg[yi - 1];
+      const double pco2 = sm.yr[0][yi], ptg = sm.yr[1][yi], pig = sm.yr[2][yi], psg = sm.yr[3][yi];
+      const bool carry = yi > 0 && pco2 == sm.yr[0][yi - 1] && ptg == sm.yr[1][yi - 1] && pig == sm.yr[2][yi - 1] && psg == sm.yr[3][yi - 1];
       if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
       else { a.co2 = pco2; a.tg = ptg; a.ig = pig; a.sg = psg; }
       const double* ccy = T.cc + (size_t)yi * kTypes * kYears * kMults * 2;
@@ -697,15 +718,16 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
         const double t12v = T.t12[(size_t)yi * kTypes + t];
         EG_T0();
 #ifdef EG_STAMPS
-        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, stamps);
+        double m03v = 0.0;
+        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, &m03v, stamps);
         stamps[11] += 1;
 #else
-        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr);
+        double m03v = 0.0;
+        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, &m03v);
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
-        const double m03v = T.m03[cell];
         if (lane == 0) {
           sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
           sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
@@ -765,7 +787,7 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     EG_T0();
     const State s = state_of(a);
     const double gen = (a.tg + a.ig) + a.sg;
-    const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * T.carbon_price[yi];
+    const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * sm.yr[8][yi];
     const double total_capital = a.gcost + a.ocost;
     const double yearly_capital = yi == 0 ? total_capital : total_capital - (a.gcost_prev + a.ocost_prev);
     double sales = 0.0;
@@ -782,9 +804,9 @@ __global__ void __launch_bounds__(kWave) k_rollout(DevTables T, DevSnapshot S, D
     }
     if (S.write_yearly && O.yearly != nullptr && lane == 0) {   // one lane: 21 adjacent 8-byte stores (merged pairwise)
       double* row = O.yearly + ((size_t)e * kYears + yi) * EG_YEARLY_FIELDS;
-      row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = T.population[yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
+      row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = sm.yr[6][yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
       row[EG_Y_BALANCE] = s.balance; row[EG_Y_OPINION] = s.opinion; row[EG_Y_YEARLY_CAPITAL] = yearly_capital;
-      row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = T.inflation[yi]; row[EG_Y_CO2] = a.co2;
+      row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = sm.yr[7][yi]; row[EG_Y_CO2] = a.co2;
       row[EG_Y_OFFSET] = a.offs; row[EG_Y_NET_CO2] = s.net; row[EG_Y_YEARLY_CREDIT] = credit; row[EG_Y_TOTAL_CREDIT] = total_credit;
       row[EG_Y_YEARLY_SALES] = sales; row[EG_Y_TOTAL_SALES] = total_sales; row[EG_Y_ACTIVE_GENS] = (double)a.opcnt;
       row[EG_Y_UPGRADE_COSTS] = 0.0; row[EG_Y_CLOSURE_COSTS] = 0.0;   // identically 0 (simulation.rs:41-42)
@@ -833,7 +855,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   load_static_tables(T, lane);
   __syncthreads();
   double score = 0.0;
-  const int cell = place_search(T, lane, yi, type, n_extra, &score);
+  const int cell = place_search(T, lane, yi, type, n_extra, &score, nullptr);
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 

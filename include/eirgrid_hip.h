@@ -45,8 +45,8 @@ extern "C" {
 #define EG_YEARLY_FIELDS 21
 
 /* per-episode capacities of the device logs (an episode that exceeds one ends with status EG_EP_OVERFLOW) */
-#define EG_MAX_GENS 1024
-#define EG_MAX_OFFSETS 1024
+#define EG_MAX_GENS 512
+#define EG_MAX_OFFSETS 512
 #define EG_RUN_CAP 2048
 #define EG_DEF_CAP 1024
 #define EG_ACT_CAP 1024
