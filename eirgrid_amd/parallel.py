@@ -74,12 +74,22 @@ def exchange_packet(packet, dist=None):
         score, index, cand = parse_candidate(host[nstat:])
         return host[:nstat].view(np.int64).copy(), (cand if index >= 0 else None)
     ws = dist.get_world_size()
-    stats = packet[:nstat].view(torch.int64)
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM)                    # the one all-reduce of the update
-    cands = torch.empty(ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
-    dist.all_gather_into_tensor(cands, packet[nstat:].contiguous())
-    host_stats = stats.cpu().numpy().copy()
-    host_cands = cands.cpu().numpy().reshape(ws, N.CANDIDATE_BYTES)
+    if dist.get_backend() == "gloo":          # CPU rehearsal of the same exchange (tests; no RCCL involved)
+        host = packet.cpu()
+        stats = host[:nstat].view(torch.int64).clone()
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        mine = host[nstat:].clone()
+        gathered = [torch.empty_like(mine) for _ in range(ws)]
+        dist.all_gather(gathered, mine)
+        host_stats = stats.numpy().copy()
+        host_cands = torch.stack(gathered).numpy()
+    else:
+        stats = packet[:nstat].view(torch.int64)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)                # the one all-reduce of the update (RCCL over xGMI)
+        cands = torch.empty(ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
+        dist.all_gather_into_tensor(cands, packet[nstat:].contiguous())
+        host_stats = stats.cpu().numpy().copy()
+        host_cands = cands.cpu().numpy().reshape(ws, N.CANDIDATE_BYTES)
     parsed = [parse_candidate(host_cands[r]) for r in range(ws)]
     win = pick_candidate([(p[0], p[1]) for p in parsed])
     return host_stats, (parsed[win[0]][2] if win is not None else None)

@@ -140,3 +140,18 @@ def test_fused_packet_matches_separate_kernels(engine):
     assert cand[2][:nr.sum()].tobytes() == rl[:nr.sum()].tobytes() and cand[4][:nd.sum()].tobytes() == dl[:nd.sum()].tobytes()
     host = packet.cpu().numpy()[8 * N.STATS_LEN:]
     assert host[0:8].view(np.float64)[0] == scores[b] and host[8:16].view(np.int64)[0] == 7000 + b
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py end to end (sharded global indices, stats all-reduce, candidate gather, identical
+    replicas) with two ranks sharing cuda:0 over gloo — RCCL itself needs the driver's multi-GPU node."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--episodes", "256",
+           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["episodes_ok_last_batch"] == 256
