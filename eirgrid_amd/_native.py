@@ -61,6 +61,7 @@ EXPORTS = [
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
     "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
+    "eg_policy_save_json", "eg_policy_load_json",
 ]
 
 _lib = None
@@ -129,6 +130,10 @@ def lib():
     L.eg_policy_get_list.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u8p, C.c_int32]
     L.eg_policy_apply_episode.restype = C.c_int32
     L.eg_policy_apply_episode.argtypes = [C.c_void_p, _dp, _i32p, _u8p, _i32p, _u8p, C.c_uint64]
+    L.eg_policy_save_json.restype = C.c_int32
+    L.eg_policy_save_json.argtypes = [C.c_void_p, C.c_char_p]
+    L.eg_policy_load_json.restype = C.c_void_p
+    L.eg_policy_load_json.argtypes = [C.c_char_p]
     L.eg_score_metrics.restype = C.c_double
     L.eg_score_metrics.argtypes = [_dp, C.c_int32]
     _lib = L

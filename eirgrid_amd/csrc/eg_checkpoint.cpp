@@ -1,0 +1,298 @@
+// eg_checkpoint.cpp — ActionWeights checkpoints in the reference's JSON schema.
+//
+// Schema = serde's rendering of SerializableWeights (ai/learning/serialization.rs:38-51): year keys are strings, every
+// table entry is a 2-element array [SerializableAction, weight] (ai/actions/serializable_action.rs:6-13), the best_*
+// members are nullable, and action_count_weights is NOT part of the file — after a load the count table is absent and
+// sample_additional_actions takes the heuristic branch, exactly as in the reference
+// (ai/learning/weights/serialization.rs:474, sampling.rs:423-442).  Written pretty-printed with two-space indentation
+// like serde_json::to_string_pretty (:133); HashMap order is unspecified in the reference, here years ascend and
+// actions follow the canonical table order.  A file written here loads in the reference's load_from_file, and a
+// file written by the reference loads here.
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+#include "eg_internal.h"
+#include "eg_policy_internal.h"
+
+namespace {
+
+const char* kTypeName[EG_N_TYPES] = {"OnshoreWind", "OffshoreWind", "DomesticSolar", "CommercialSolar", "UtilitySolar", "Nuclear",
+                                     "CoalPlant", "GasCombinedCycle", "GasPeaker", "Biomass", "HydroDam", "PumpedStorage",
+                                     "BatteryStorage", "TidalGenerator", "WaveEnergy"};   // models/generator.rs:63-83
+const char* kOffsetName[4] = {"Forest", "Wetland", "ActiveCapture", "CarbonCredit"};        // canonical order, core.rs:100-114
+const int kMultPercent[3] = {100, 120, 150};
+const int kDeficitAction[ND] = {24, 21, 36, 33, 27, 0, 3, 12, 30, 15, 6, 9, 39, 42, 60};   // deficit slot -> main-table index
+
+// ---------------------------------------------------------------- writer
+std::string fmt_f64(double v) {   // shortest representation that round-trips, with a ".0" on integers like serde_json/ryu
+  if (!std::isfinite(v)) return "null";
+  char buf[40];
+  for (int p = 1; p <= 17; ++p) {
+    std::snprintf(buf, sizeof(buf), "%.*g", p, v);
+    if (std::strtod(buf, nullptr) == v) break;
+  }
+  std::string s(buf);
+  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
+  return s;
+}
+struct Writer {
+  std::string out; int depth = 0;
+  void nl() { out += '\n'; out.append(size_t(depth) * 2, ' '); }
+  void action(int a) {   // SerializableAction::from (serializable_action.rs:15-66)
+    const char* type; std::string gen = "null", id = "null", pct = "null", off = "null", mult = "null";
+    if (a < 45) { type = "AddGenerator"; gen = std::string("\"") + kTypeName[a / 3] + "\""; mult = std::to_string(kMultPercent[a % 3]); }
+    else if (a < 57) { type = "AddCarbonOffset"; off = std::string("\"") + kOffsetName[(a - 45) / 3] + "\""; mult = std::to_string(kMultPercent[(a - 45) % 3]); }
+    else if (a == 57) { type = "UpgradeEfficiency"; id = "\"\""; }
+    else if (a == 58) { type = "AdjustOperation"; id = "\"\""; pct = "0"; }
+    else if (a == 59) { type = "CloseGenerator"; id = "\"\""; }
+    else type = "DoNothing";
+    out += '{'; ++depth;
+    nl(); out += std::string("\"action_type\": \"") + type + "\",";
+    nl(); out += "\"generator_type\": " + gen + ",";
+    nl(); out += "\"generator_id\": " + id + ",";
+    nl(); out += "\"operation_percentage\": " + pct + ",";
+    nl(); out += "\"offset_type\": " + off + ",";
+    nl(); out += "\"cost_multiplier\": " + mult;
+    --depth; nl(); out += '}';
+  }
+  template <typename Row>
+  void table(const Row* rows, int n, const int* action_of) {   // HashMap<u32, Vec<(SerializableAction, f64)>>
+    out += '{'; ++depth;
+    for (int y = 0; y < Y; ++y) {
+      nl(); out += "\"" + std::to_string(2025 + y) + "\": ["; ++depth;
+      for (int i = 0; i < n; ++i) {
+        nl(); out += '['; ++depth; nl(); action(action_of ? action_of[i] : i); out += ','; nl(); out += fmt_f64(rows[y][i]); --depth; nl(); out += ']';
+        if (i + 1 < n) out += ',';
+      }
+      --depth; nl(); out += ']';
+      if (y + 1 < Y) out += ',';
+    }
+    --depth; nl(); out += '}';
+  }
+  void lists(const std::array<ActionList, Y>& l) {   // HashMap<u32, Vec<SerializableAction>>
+    out += '{'; ++depth;
+    for (int y = 0; y < Y; ++y) {
+      nl(); out += "\"" + std::to_string(2025 + y) + "\": [";
+      if (!l[y].empty()) {
+        ++depth;
+        for (size_t i = 0; i < l[y].size(); ++i) { nl(); action(l[y][i]); if (i + 1 < l[y].size()) out += ','; }
+        --depth; nl();
+      }
+      out += ']';
+      if (y + 1 < Y) out += ',';
+    }
+    --depth; nl(); out += '}';
+  }
+};
+
+// ---------------------------------------------------------------- minimal JSON reader
+struct Json {
+  enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+  bool b = false; double num = 0.0; std::string str;
+  std::vector<Json> arr; std::vector<std::pair<std::string, Json>> obj;
+  const Json* get(const char* key) const { for (auto& kv : obj) if (kv.first == key) return &kv.second; return nullptr; }
+};
+struct Parser {
+  const char* p; const char* end; std::string err;
+  void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p; }
+  bool fail(const char* m) { if (err.empty()) err = m; return false; }
+  bool string(std::string& s) {
+    if (p >= end || *p != '"') return fail("expected string");
+    ++p; s.clear();
+    while (p < end && *p != '"') {
+      if (*p == '\\') {
+        if (++p >= end) return fail("bad escape");
+        switch (*p) { case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'r': s += '\r'; break; case 'b': s += '\b'; break;
+                      case 'f': s += '\f'; break; case 'u': { if (end - p < 5) return fail("bad \\u"); unsigned c = std::strtoul(std::string(p + 1, 4).c_str(), nullptr, 16); s += char(c < 128 ? c : '?'); p += 4; break; }
+                      default: s += *p; }
+        ++p;
+      } else s += *p++;
+    }
+    if (p >= end) return fail("unterminated string");
+    ++p; return true;
+  }
+  bool value(Json& j, int depth = 0) {
+    if (depth > 64) return fail("nesting too deep");
+    ws(); if (p >= end) return fail("unexpected end");
+    if (*p == '{') {
+      j.kind = Json::Obj; ++p; ws();
+      if (p < end && *p == '}') { ++p; return true; }
+      while (true) {
+        ws(); std::string k; if (!string(k)) return false;
+        ws(); if (p >= end || *p != ':') return fail("expected ':'"); ++p;
+        j.obj.emplace_back(k, Json()); if (!value(j.obj.back().second, depth + 1)) return false;
+        ws(); if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == '}') { ++p; return true; }
+        return fail("expected ',' or '}'");
+      }
+    }
+    if (*p == '[') {
+      j.kind = Json::Arr; ++p; ws();
+      if (p < end && *p == ']') { ++p; return true; }
+      while (true) {
+        j.arr.emplace_back(); if (!value(j.arr.back(), depth + 1)) return false;
+        ws(); if (p < end && *p == ',') { ++p; continue; }
+        if (p < end && *p == ']') { ++p; return true; }
+        return fail("expected ',' or ']'");
+      }
+    }
+    if (*p == '"') { j.kind = Json::Str; return string(j.str); }
+    if (end - p >= 4 && !std::strncmp(p, "null", 4)) { p += 4; j.kind = Json::Null; return true; }
+    if (end - p >= 4 && !std::strncmp(p, "true", 4)) { p += 4; j.kind = Json::Bool; j.b = true; return true; }
+    if (end - p >= 5 && !std::strncmp(p, "false", 5)) { p += 5; j.kind = Json::Bool; j.b = false; return true; }
+    char* e = nullptr; errno = 0; double v = std::strtod(p, &e);
+    if (e == p) return fail("bad token");
+    j.kind = Json::Num; j.num = v; p = e; return true;
+  }
+};
+
+int action_index(const Json& a) {   // inverse of Writer::action; -1 = not representable in the canonical table
+  const Json* t = a.get("action_type");
+  if (!t || t->kind != Json::Str) return -1;
+  const Json* mult = a.get("cost_multiplier");
+  int m = 0;
+  if (mult && mult->kind == Json::Num) { int pc = int(mult->num); m = pc == 100 ? 0 : pc == 120 ? 1 : pc == 150 ? 2 : -1; }
+  if (t->str == "AddGenerator") {
+    const Json* g = a.get("generator_type");
+    if (!g || g->kind != Json::Str) return 3 * 8;            // serialization.rs:163-165: GasPeaker, default multiplier
+    for (int i = 0; i < EG_N_TYPES; ++i) if (g->str == kTypeName[i]) return m < 0 ? -1 : 3 * i + m;
+    return -2;                                               // unknown generator type: an error in the reference too
+  }
+  if (t->str == "AddCarbonOffset") {
+    const Json* o = a.get("offset_type");
+    int ot = 0;                                              // unknown names fall back to Forest (serialization.rs:186)
+    if (o && o->kind == Json::Str) for (int i = 0; i < 4; ++i) if (o->str == kOffsetName[i]) ot = i;
+    return m < 0 ? -1 : 45 + 3 * ot + m;
+  }
+  const Json* id = a.get("generator_id");
+  const bool empty_id = !id || id->kind != Json::Str || id->str.empty();
+  if (t->str == "UpgradeEfficiency") return empty_id ? 57 : -1;
+  if (t->str == "AdjustOperation") return empty_id ? 58 : -1;
+  if (t->str == "CloseGenerator") return empty_id ? 59 : -1;
+  if (t->str == "DoNothing") return 60;
+  return -2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t eg_policy_save_json(const eg_policy* p, const char* path) {   // ai/learning/weights/serialization.rs:29-139
+  if (!p || !path) return EG_ERR_BAD_ARG;
+  Writer w;
+  w.out += '{'; ++w.depth;
+  w.nl(); w.out += "\"weights\": "; w.table(p->w.data(), NA, nullptr); w.out += ',';
+  w.nl(); w.out += "\"learning_rate\": " + fmt_f64(p->learning_rate) + ",";
+  w.nl(); w.out += "\"best_metrics\": ";
+  if (p->has_best) {
+    w.out += '{'; ++w.depth;
+    w.nl(); w.out += "\"final_net_emissions\": " + fmt_f64(p->best_metrics[0]) + ",";
+    w.nl(); w.out += "\"average_public_opinion\": " + fmt_f64(p->best_metrics[1]) + ",";
+    w.nl(); w.out += "\"total_cost\": " + fmt_f64(p->best_metrics[2]) + ",";
+    w.nl(); w.out += "\"power_reliability\": " + fmt_f64(p->best_metrics[3]);
+    --w.depth; w.nl(); w.out += '}';
+  } else w.out += "null";
+  w.out += ',';
+  w.nl(); w.out += "\"best_weights\": "; if (p->has_best_weights) w.table(p->best_w.data(), NA, nullptr); else w.out += "null"; w.out += ',';
+  w.nl(); w.out += "\"best_actions\": "; if (p->has_best_actions) w.lists(p->best_actions); else w.out += "null"; w.out += ',';
+  w.nl(); w.out += "\"iteration_count\": " + std::to_string(p->iteration_count) + ",";
+  w.nl(); w.out += "\"iterations_without_improvement\": " + std::to_string(p->stall) + ",";
+  w.nl(); w.out += "\"exploration_rate\": " + fmt_f64(p->exploration_rate) + ",";
+  w.nl(); w.out += "\"deficit_weights\": "; w.table(p->dw.data(), ND, kDeficitAction); w.out += ',';
+  w.nl(); w.out += "\"best_deficit_actions\": "; if (p->has_best_deficit) w.lists(p->best_deficit); else w.out += "null"; w.out += ',';
+  w.nl(); w.out += "\"optimization_mode\": null,";     // always None inside ActionWeights (Q3)
+  w.nl(); w.out += "\"improvement_history\": ";
+  if (p->improvement_history.empty()) w.out += "null";
+  else {
+    w.out += '['; ++w.depth;
+    for (size_t i = 0; i < p->improvement_history.size(); ++i) {
+      const ImprovementRecord& r = p->improvement_history[i];
+      w.nl(); w.out += '{'; ++w.depth;
+      w.nl(); w.out += "\"iteration\": " + std::to_string(r.iteration) + ",";
+      w.nl(); w.out += "\"score\": " + fmt_f64(r.score) + ",";
+      w.nl(); w.out += "\"net_emissions\": " + fmt_f64(r.net_emissions) + ",";
+      w.nl(); w.out += "\"total_cost\": " + fmt_f64(r.total_cost) + ",";
+      w.nl(); w.out += "\"public_opinion\": " + fmt_f64(r.public_opinion) + ",";
+      w.nl(); w.out += "\"power_reliability\": " + fmt_f64(r.power_reliability) + ",";
+      w.nl(); w.out += "\"timestamp\": \"" + r.timestamp + "\"";
+      --w.depth; w.nl(); w.out += '}';
+      if (i + 1 < p->improvement_history.size()) w.out += ',';
+    }
+    --w.depth; w.nl(); w.out += ']';
+  }
+  --w.depth; w.nl(); w.out += '}';
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) { eg::set_error(std::string("eg_policy_save_json: cannot open ") + path); return EG_ERR_BAD_ARG; }
+  f << w.out;
+  return f.good() ? EG_OK : EG_ERR_BAD_ARG;
+}
+
+eg_policy* eg_policy_load_json(const char* path) {   // ai/learning/weights/serialization.rs:140-493
+  if (!path) return nullptr;
+  std::ifstream f(path, std::ios::binary);
+  if (!f) { eg::set_error(std::string("eg_policy_load_json: cannot open ") + path); return nullptr; }
+  std::stringstream ss; ss << f.rdbuf();
+  const std::string text = ss.str();
+  Parser ps{text.data(), text.data() + text.size(), {}};
+  Json root;
+  if (!ps.value(root) || root.kind != Json::Obj) { eg::set_error("eg_policy_load_json: " + (ps.err.empty() ? std::string("not an object") : ps.err)); return nullptr; }
+  std::unique_ptr<eg_policy> p(eg_policy_new());
+  std::string problem;
+  auto load_table = [&](const Json* t, auto& rows, int n, bool deficit, bool strict) -> bool {
+    if (!t || t->kind != Json::Obj) return false;
+    for (auto& kv : t->obj) {
+      const int y = std::atoi(kv.first.c_str()) - 2025;
+      if (y < 0 || y >= Y || kv.second.kind != Json::Arr) continue;
+      for (const Json& entry : kv.second.arr) {
+        if (entry.kind != Json::Arr || entry.arr.size() != 2 || entry.arr[1].kind != Json::Num) continue;
+        int a = action_index(entry.arr[0]);
+        if (a == -2 && strict) { problem = "unknown action or generator type in weights"; return false; }   // InvalidData in the reference
+        if (a < 0) continue;
+        if (deficit) { int slot = -1; for (int i = 0; i < ND; ++i) if (kDeficitAction[i] == a) slot = i; a = slot; if (a < 0) continue; }
+        if (a < n) rows[y][a] = entry.arr[1].num;
+      }
+    }
+    return true;
+  };
+  if (!load_table(root.get("weights"), p->w, NA, false, true)) { eg::set_error("eg_policy_load_json: " + (problem.empty() ? std::string("missing weights") : problem)); return nullptr; }
+  load_table(root.get("deficit_weights"), p->dw, ND, true, false);   // absent/empty -> defaults (serialization.rs:262-279)
+  auto num = [&](const char* k, double d) { const Json* j = root.get(k); return j && j->kind == Json::Num ? j->num : d; };
+  p->learning_rate = num("learning_rate", 0.2); p->exploration_rate = num("exploration_rate", 0.2);
+  p->iteration_count = uint32_t(num("iteration_count", 0)); p->stall = uint32_t(num("iterations_without_improvement", 0));
+  if (const Json* bm = root.get("best_metrics"); bm && bm->kind == Json::Obj) {
+    const char* keys[4] = {"final_net_emissions", "average_public_opinion", "total_cost", "power_reliability"};
+    p->has_best = true;
+    for (int i = 0; i < 4; ++i) { const Json* v = bm->get(keys[i]); p->best_metrics[i] = v && v->kind == Json::Num ? v->num : 0.0; }
+  }
+  if (const Json* bw = root.get("best_weights"); bw && bw->kind == Json::Obj) { p->best_w = p->w; p->has_best_weights = load_table(bw, p->best_w, NA, false, false); }
+  auto load_lists = [&](const Json* t, std::array<ActionList, Y>& l) -> bool {
+    if (!t || t->kind != Json::Obj) return false;
+    for (auto& kv : t->obj) {
+      const int y = std::atoi(kv.first.c_str()) - 2025;
+      if (y < 0 || y >= Y || kv.second.kind != Json::Arr) continue;
+      l[y].clear();
+      for (const Json& a : kv.second.arr) { const int idx = action_index(a); if (idx >= 0) l[y].push_back(uint8_t(idx)); }
+    }
+    return true;
+  };
+  p->has_best_actions = load_lists(root.get("best_actions"), p->best_actions);
+  p->has_best_deficit = load_lists(root.get("best_deficit_actions"), p->best_deficit);
+  if (const Json* h = root.get("improvement_history"); h && h->kind == Json::Arr)
+    for (const Json& r : h->arr) {
+      if (r.kind != Json::Obj) continue;
+      auto g = [&](const char* k) { const Json* v = r.get(k); return v && v->kind == Json::Num ? v->num : 0.0; };
+      const Json* ts = r.get("timestamp");
+      p->improvement_history.push_back({uint32_t(g("iteration")), g("score"), g("net_emissions"), g("total_cost"), g("public_opinion"),
+                                        g("power_reliability"), ts && ts->kind == Json::Str ? ts->str : std::string()});
+    }
+  p->has_cw = false;   // action_count_weights is not part of the file (serialization.rs:474)
+  return p.release();
+}
+
+}  // extern "C"

@@ -11,14 +11,13 @@
 #include <vector>
 
 #include "eg_internal.h"
+#include "eg_policy_internal.h"
 
 namespace {
 
-constexpr int Y = EG_YEARS, NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, NC = EG_N_COUNTS;
 constexpr double kMinW = 0.0001, kMaxW = 0.999;          // ai/learning/constants.rs:14-15
 constexpr double kMaxEmissions = 1000000.0, kMaxCost = 50000000000.0;   // config/constants.rs:114-115
 
-using ActionList = std::vector<uint8_t>;
 
 // initial weights per generator type, enum order (ai/learning/constants.rs:46-60)
 const double kTypeWeight[EG_N_TYPES] = {0.08, 0.08, 0.05, 0.05, 0.08, 0.03, 0.04, 0.06, 0.02, 0.04, 0.06, 0.06, 0.07, 0.05, 0.05};
@@ -66,24 +65,6 @@ struct HostRng {
 };
 
 }  // namespace
-
-struct eg_policy {
-  std::array<std::array<double, NA>, Y> w{};
-  std::array<std::array<double, ND>, Y> dw{};
-  std::array<std::array<double, NC>, Y> cw{};
-  bool has_cw = true;
-  double learning_rate = 0.2, exploration_rate = 0.2;   // constants.rs:17-18
-  bool has_best = false;
-  std::array<double, 4> best_metrics{};
-  bool has_best_weights = false;
-  std::array<std::array<double, NA>, Y> best_w{};
-  bool has_best_actions = false, has_best_deficit = false;
-  std::array<ActionList, Y> best_actions, best_deficit, cur_run, cur_def;
-  uint32_t iteration_count = 0, stall = 0;
-  // flattened replay data handed out by eg_policy_snapshot_view
-  mutable std::vector<int32_t> flat_best_count, flat_bestd_count;
-  mutable std::vector<uint8_t> flat_best, flat_bestd;
-};
 
 extern "C" {
 
@@ -238,6 +219,7 @@ int32_t eg_policy_apply_episode(eg_policy* p, const double metrics[4], const int
   const double current_score = eg_score_metrics(metrics, 0);
   p->iteration_count += 1;
   if (!p->has_best || current_score > eg_score_metrics(p->best_metrics.data(), 0)) {
+    p->record_improvement(current_score, metrics);
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = metrics[i];
     p->has_best_weights = true; p->best_w = p->w;
     p->best_actions = p->cur_run; p->best_deficit = p->cur_def;
@@ -309,6 +291,7 @@ int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double
   if (cand_metrics && cand_n_run && cand_n_def && n_ok > 0)
     improved = !p->has_best || eg_score_metrics(cand_metrics, 0) > eg_score_metrics(p->best_metrics.data(), 0);
   if (improved) {
+    p->record_improvement(eg_score_metrics(cand_metrics, 0), cand_metrics);
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = cand_metrics[i];
     p->has_best_weights = true; p->best_w = p->w;
     for (int y = 0, rp = 0, dp = 0; y < Y; ++y) {

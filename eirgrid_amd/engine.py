@@ -73,8 +73,20 @@ class ActionWeights:
               best_net_emissions=5, best_opinion=6, best_cost=7, best_reliability=8, has_best_actions=9,
               has_best_deficit_actions=10, has_count_weights=11)
 
-    def __init__(self):
-        self.h = N.lib().eg_policy_new()
+    def __init__(self, handle=None):
+        self.h = handle if handle is not None else N.lib().eg_policy_new()
+
+    def save_to_file(self, path: str) -> None:
+        """ai/learning/weights/serialization.rs:29-139 — pretty JSON in the reference's SerializableWeights schema."""
+        N.check(N.lib().eg_policy_save_json(self.h, str(path).encode()), "eg_policy_save_json")
+
+    @staticmethod
+    def load_from_file(path: str) -> "ActionWeights":
+        """ai/learning/weights/serialization.rs:140-493."""
+        h = N.lib().eg_policy_load_json(str(path).encode())
+        if not h:
+            raise N.EirgridError(N.lib().eg_last_error().decode())
+        return ActionWeights(h)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -212,6 +212,11 @@ int32_t eg_policy_apply_episode(eg_policy *, const double metrics[4], const int3
 int32_t eg_policy_apply_reduced(eg_policy *, const int64_t *stats, const double cand_metrics[4], const int32_t *cand_n_run,
                                 const uint8_t *cand_run_log, const int32_t *cand_n_def, const uint8_t *cand_def_log,
                                 uint64_t noise_seed);
+/* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
+ * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
+ * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */
+int32_t eg_policy_save_json(const eg_policy *, const char *path);
+eg_policy *eg_policy_load_json(const char *path);   /* NULL + eg_last_error() on failure */
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus
