@@ -217,6 +217,16 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+typedef short short2v __attribute__((ext_vector_type(2)));
+// index into the 13x13 factor table of a radius class: min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)
+__device__ __forceinline__ int penalty_index(short2v cpk, int gen_packed) {
+  short2v g; __builtin_memcpy(&g, &gen_packed, 4);
+  short2v d = cpk - g;
+  d = __builtin_elementwise_max(d, (short2v)(0, 0) - d);
+  d = __builtin_elementwise_min(d, (short2v)(12, 12));
+  return (int)d.x * 13 + (int)d.y;
+}
+
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
                                             double* best_m03, unsigned long long* stamps = nullptr) {
   const int info = sm.type_info[type];
@@ -245,34 +255,24 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 #endif
     const int ci = cell_cur / kGrid, cj = cell_cur - ci * kGrid;
     double s = te_cur;
+    const short2v cpk = {(short)ci, (short)cj};
     for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
       const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : 0;
       const int mi = mine / kGrid;
-      const int mp = mi | ((mine - mi * kGrid) << 8);                // (gi, gj) packed: one readlane per generator
+      const int mp = mi | ((mine - mi * kGrid) << 16);               // (gi, gj) as two int16: one readlane per generator
       const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
       // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
-      // exactly, so out-of-range generators multiply by 1.0 instead of branching.  Four generators per trip: the
-      // index arithmetic and LDS reads of the four are independent, only the four multiplies are a chain.
+      // exactly, so out-of-range generators multiply by 1.0 instead of branching.  (|di|, |dj|) are computed with
+      // packed 16-bit ops and turned into the table index by one dot product.  Four generators per trip: their index
+      // arithmetic and LDS reads are independent, only the four multiplies form a chain.
       int j = 0;
       for (; j + 4 <= cnt; j += 4) {
         double f[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = __builtin_amdgcn_readlane(mp, j + u);
-          int di = ci - (p & 0xFF), dj = cj - (p >> 8);
-          di = di < 0 ? -di : di; dj = dj < 0 ? -dj : dj;
-          di = di > 12 ? 12 : di; dj = dj > 12 ? 12 : dj;
-          f[u] = dr[di * 13 + dj];
-        }
+        for (int u = 0; u < 4; ++u) f[u] = dr[penalty_index(cpk, __builtin_amdgcn_readlane(mp, j + u))];
         s = s * f[0]; s = s * f[1]; s = s * f[2]; s = s * f[3];
       }
-      for (; j < cnt; ++j) {
-        const int p = __builtin_amdgcn_readlane(mp, j);
-        int di = ci - (p & 0xFF), dj = cj - (p >> 8);
-        di = di < 0 ? -di : di; dj = dj < 0 ? -dj : dj;
-        di = di > 12 ? 12 : di; dj = dj > 12 ? 12 : dj;
-        s = s * dr[di * 13 + dj];
-      }
+      for (; j < cnt; ++j) s = s * dr[penalty_index(cpk, __builtin_amdgcn_readlane(mp, j))];
     }
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
