@@ -222,8 +222,9 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int penalty_index(short2v cpk, int gen_packed) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
   short2v d = cpk - g;
-  d = __builtin_elementwise_max(d, (short2v)(0, 0) - d);
-  d = __builtin_elementwise_min(d, (short2v)(12, 12));
+  const short2v zero = {0, 0}, cap = {12, 12};
+  d = __builtin_elementwise_max(d, zero - d);
+  d = __builtin_elementwise_min(d, cap);
   return (int)d.x * 13 + (int)d.y;
 }
 
