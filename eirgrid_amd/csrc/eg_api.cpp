@@ -259,6 +259,9 @@ int32_t eg_host_tables_i32(const eg_host_tables* h, const char* name, const int3
 int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o) {
   if (!c || !s || !s->weights || !s->deficit_weights) { set_error("eg_upload_snapshot: bad argument"); return EG_ERR_BAD_ARG; }
   if (o && o->enable_construction_delays) { set_error("enable_construction_delays is not implemented on the device (SURVEY §8(f) N4)"); return EG_ERR_UNSUPPORTED; }
+  // the device walks rely on strictly positive weights (the reference clamps every weight to [1e-4, 0.999])
+  for (int i = 0; i < EG_YEARS * EG_N_ACTIONS; ++i) if (!(s->weights[i] > 0.0)) { set_error("eg_upload_snapshot: weights must be > 0"); return EG_ERR_BAD_ARG; }
+  for (int i = 0; i < EG_YEARS * EG_N_DEFICIT; ++i) if (!(s->deficit_weights[i] > 0.0)) { set_error("eg_upload_snapshot: deficit weights must be > 0"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
   const bool have_lists = s->has_best && s->best_count && s->best_actions && s->best_deficit_count && s->best_deficit_actions;
   int32_t off[28] = {0}, offd[28] = {0};

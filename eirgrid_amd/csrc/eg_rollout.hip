@@ -217,6 +217,29 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+// max over the 64 lanes of a non-negative double, returned in every lane.  DPP row shifts / row broadcasts move the two
+// dwords; each step keeps the lane's own value where a DPP source lane does not exist (old = self, bound_ctrl off), so
+// after the six steps lane 63 holds the maximum of all lanes.
+__device__ __forceinline__ double wave_max_f64(double v) {
+#define EG_DPP_MAX_STEP(ctrl, row_mask, bank_mask)                                                              \
+  {                                                                                                             \
+    const int lo = __double2loint(v), hi = __double2hiint(v);                                                   \
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, row_mask, bank_mask, false);                      \
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, row_mask, bank_mask, false);                      \
+    const double o = __hiloint2double(ohi, olo);                                                                \
+    v = o > v ? o : v;                                                                                          \
+  }
+  EG_DPP_MAX_STEP(0x111, 0xf, 0xf)   // row_shr:1
+  EG_DPP_MAX_STEP(0x112, 0xf, 0xf)   // row_shr:2
+  EG_DPP_MAX_STEP(0x113, 0xf, 0xf)   // row_shr:3
+  EG_DPP_MAX_STEP(0x114, 0xf, 0xe)   // row_shr:4 bank_mask:0xe
+  EG_DPP_MAX_STEP(0x118, 0xf, 0xc)   // row_shr:8 bank_mask:0xc
+  EG_DPP_MAX_STEP(0x142, 0xa, 0xf)   // row_bcast:15 row_mask:0xa
+  EG_DPP_MAX_STEP(0x143, 0xc, 0xf)   // row_bcast:31 row_mask:0xc
+#undef EG_DPP_MAX_STEP
+  return readlane_f64(v, 63);
+}
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 // index into the 13x13 factor table of a radius class: min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)
 __device__ __forceinline__ int penalty_index(short2v cpk, int gen_packed) {
@@ -282,9 +305,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     s = (s * cf_cur) * size_factor;
     if (r >= kCells) s = 0.0;
     if (__any(s > best || (s == best && s > 0.0 && cell_cur < best_c))) {
-      double wmax = s;
-#pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) { const double other = __shfl_xor(wmax, sh); wmax = other > wmax ? other : wmax; }
+      const double wmax = wave_max_f64(s);
       int win_c = s == wmax ? cell_cur : kCells;
       const unsigned long long holders = __ballot(s == wmax);
       if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell_cur, __ffsll((long long)holders) - 1);
@@ -402,15 +423,18 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
     return pick;
   }
   double v = rng_f64(r, lane) * total;
-  int pick = -1;                      // eight entries per trip, branch-free inside: the LDS reads pipeline
-  for (int a0 = 0; a0 < EG_N_ACTIONS && pick < 0; a0 += 8) {
+  // Every weight is >= MIN_WEIGHT > 0, so the running value only decreases: the entry at which it first reaches <= 0 is
+  // the number of entries after which it was still positive.  Eight entries per trip, branch-free inside.
+  int pick = 0;
+  for (int a0 = 0; a0 < EG_N_ACTIONS; a0 += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int a = a0 + u;
-      if (a < EG_N_ACTIONS) { v -= sm.w[a]; pick = (pick < 0 && v <= 0.0) ? a : pick; }
+      if (a < EG_N_ACTIONS) { v -= sm.w[a]; pick += v > 0.0 ? 1 : 0; }
     }
+    if (!(v > 0.0)) break;
   }
-  return pick >= 0 ? pick : 3 * kPeaker;
+  return pick < EG_N_ACTIONS ? pick : 3 * kPeaker;
 }
 __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:315-377
   const bool explore = rng_f64(r, lane) < S.exploration_rate;
@@ -424,10 +448,10 @@ __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot
   const double total = tot.deficit;
   if (total <= 0.0) return 3 * kPeaker;
   double v = rng_f64(r, lane) * total;
-  int pick = -1;
+  int pick = 0;
 #pragma unroll 7
-  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; pick = (pick < 0 && v <= 0.0) ? i : pick; }
-  return pick >= 0 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
+  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; pick += v > 0.0 ? 1 : 0; }
+  return pick < 14 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
 }
 
 struct Episode {   // wave-uniform bookkeeping of one episode
