@@ -64,6 +64,15 @@ static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
 
+// A workgroup is ONE wavefront, and a wave's LDS operations execute in program order, so data written to LDS by one
+// lane is visible to every lane's later reads without waiting; what is needed is only that the compiler keeps the
+// program order of the LDS accesses.  Unlike wave_sync() this does not drain vmcnt, so global loads requested ahead
+// of time and the episode's output stores stay in flight across it.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct Rng {      // register part of the stream state; key / counter / buffer live in LDS
   int index;
   unsigned int words;
@@ -91,7 +100,7 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return (v << n) 
 // Four consecutive ChaCha12 blocks (rand_chacha fills 64 words per refill), one per lane 0..3.  Not inlined: the
 // episode code draws from ~10 places and the block function is ~1.2k instructions.
 __device__ __noinline__ void rng_refill(int lane) {
-  __syncthreads();
+  wave_sync();
   if (lane < 4) {
     const unsigned long long counter = sm.rng_counter + (unsigned long long)lane;
     uint32_t s[16], x[16];
@@ -109,9 +118,9 @@ __device__ __noinline__ void rng_refill(int lane) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) sm.rng[16 * lane + i] = x[i] + s[i];
   }
-  __syncthreads();
+  wave_sync();
   if (lane == 0) sm.rng_counter += 4ull;
-  __syncthreads();
+  wave_sync();
 }
 
 __device__ void rng_seed(Rng& r, unsigned long long state, int lane) {   // rand_core 0.6.4 seed_from_u64
@@ -124,7 +133,7 @@ __device__ void rng_seed(Rng& r, unsigned long long state, int lane) {   // rand
     if (lane == 0) sm.rng_key[i] = (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
   }
   if (lane == 0) sm.rng_counter = 0ull;
-  __syncthreads();
+  wave_sync();
   r.index = 64; r.words = 0;
 }
 __device__ __forceinline__ unsigned long long rng_u64(Rng& r, int lane) {   // BlockRng::next_u64
@@ -334,15 +343,15 @@ __device__ void update_weights(const DevSnapshot& S, int lane, int action, doubl
   const double combined = S.immediate_weight * improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
   const double adj = combined > 0.0 ? 1.0 + (S.learning_rate * combined)
                                     : 1.0 / (1.0 + (S.learning_rate * dabs(combined)));
-  __syncthreads();
+  wave_sync();
   if (lane == 0) sm.w[action] = dmin(dmax(sm.w[action] * adj, kMinWeight), kMaxWeight);
-  __syncthreads();
+  wave_sync();
   if (combined < 0.0) {
     const double boost = 1.0 + (S.learning_rate * 0.1);
     if (lane < kFirstOffset && lane != action) sm.w[lane] = dmin(sm.w[lane] * boost, kMaxWeight);
-    __syncthreads();
+    wave_sync();
     if (S.noop_boost && lane == 0) sm.w[kNothing] = dmin(sm.w[kNothing] * (1.0 + S.learning_rate * 0.2), kMaxWeight);
-    __syncthreads();
+    wave_sync();
   }
 }
 __device__ void update_deficit_weights(const DevSnapshot& S, int lane, int action, double improvement) {
@@ -353,13 +362,13 @@ __device__ void update_deficit_weights(const DevSnapshot& S, int lane, int actio
   if (slot < 0) return;
   const double adj = improvement > 0.0 ? 1.0 + (S.learning_rate * improvement * 1.5)
                                        : 1.0 / (1.0 + (S.learning_rate * dabs(improvement) * 1.5));
-  __syncthreads();
+  wave_sync();
   if (lane == 0) sm.dw[slot] = dmin(dmax(sm.dw[slot] * adj, kMinWeight), kMaxWeight);
-  __syncthreads();
+  wave_sync();
   if (improvement < 0.0) {
     const double boost = 1.0 + (S.learning_rate * 0.1);
     if (lane < 14 && lane != slot) sm.dw[lane] = dmin(sm.dw[lane] * boost, kMaxWeight);
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -402,7 +411,7 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
     const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
     const double power = 1.0 + (2.0 * stagnation);
-    __syncthreads();
+    wave_sync();
     if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
       const double mine = sm.w[lane];
       int rank = 0;
@@ -411,7 +420,7 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
       sm.scaled[rank] = eg_detpow(mine, power);
       sm.ydef[128 + rank] = (uint8_t)lane;
     }
-    __syncthreads();
+    wave_sync();
     double total_scaled = 0.0;
 #pragma unroll 4
     for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
@@ -419,7 +428,7 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
     int pick = sm.ydef[128];
 #pragma unroll 4
     for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.scaled[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
-    __syncthreads();
+    wave_sync();
     return pick;
   }
   double v = rng_f64(r, lane) * total;
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     const int year = 2025 + yi;
     {  // this year's policy rows -> LDS (they were requested a year ahead: nw / ndw / ncw), then request next year's
     EG_T0();
-    __syncthreads();
+    wave_sync();
     if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
     if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
     if (lane < EG_N_COUNTS) sm.cw[lane] = ncw;
@@ -579,7 +588,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
       if (lane < EG_N_DEFICIT) ndw = S.dw[(yi + 1) * EG_N_DEFICIT + lane];
       if (S.cw != nullptr && lane < EG_N_COUNTS) ncw = S.cw[(yi + 1) * EG_N_COUNTS + lane];
     }
-    __syncthreads();
+    wave_sync();
     EG_T1(5);
     }
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
@@ -668,7 +677,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
           const double success = evaluate_impact(initial, fin);
           if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
             const double factor = 0.1 * success;
-            __syncthreads();
+            wave_sync();
             for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, lane, sm.ydef[i], factor);
             tot.deficit_valid = false;
           }
@@ -759,7 +768,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
           gen_cell[ep.ngen] = (uint16_t)cell;
           gen_pack[ep.ngen] = (uint16_t)(t | (yi << 4) | (m << 9));
         }
-        __syncthreads();
+        wave_sync();
         ep.ngen += 1;
         a.gcost += ccv.x;
         if (yi > 0) a.gcost_prev += cc_prev;
@@ -774,7 +783,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; break; }
         const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9));
         if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
-        __syncthreads();
+        wave_sync();
         ep.noff += 1;
         a.offs += T.offv[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
         a.ocost += T.offc[((size_t)yi * kOffsetTypes + ot) * kMults + m];
@@ -818,11 +827,11 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     double sales = 0.0;
     if (S.enable_energy_sales && s.balance > 0.0) { const double gwh = s.balance * 8.76; sales = gwh * 50000.0; }
     const double yearly_total = yearly_capital + 0.0 + 0.0 - credit - (S.enable_energy_sales ? sales : 0.0);
-    __syncthreads();
+    wave_sync();
     const double total_cost = yi == 0 ? yearly_total : sm.acc[0] + yearly_total;
     const double total_credit = yi == 0 ? credit : sm.acc[1] + credit;
     const double total_sales = yi == 0 ? sales : sm.acc[2] + sales;
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
       sm.acc[0] = total_cost; sm.acc[1] = total_credit; sm.acc[2] = total_sales;
       sm.acc[3] = s.net; sm.acc[4] = s.opinion; sm.acc[5] = total_capital; sm.acc[6] = s.balance;
@@ -847,7 +856,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     EG_T1(4);
   }
 
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {   // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
     O.metrics[(size_t)e * 4 + 0] = sm.acc[3];
     O.metrics[(size_t)e * 4 + 1] = sm.acc[4];
