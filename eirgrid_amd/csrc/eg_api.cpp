@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "eg_internal.h"
+#define EG_DETPOW_QUAL static inline
+#include "eg_detpow.h"
 
 namespace eg {
 namespace {
@@ -75,7 +77,10 @@ constexpr size_t kSnapW = 0;
 constexpr size_t kSnapDw = kSnapW + sizeof(double) * EG_YEARS * EG_N_ACTIONS;
 constexpr size_t kSnapCw = kSnapDw + sizeof(double) * EG_YEARS * EG_N_DEFICIT;
 constexpr size_t kSnapTotals = kSnapCw + sizeof(double) * EG_YEARS * EG_N_COUNTS;
-constexpr size_t kSnapMask = kSnapTotals + sizeof(double) * EG_YEARS * 3;
+constexpr size_t kSnapScaled = kSnapTotals + sizeof(double) * EG_YEARS * 3;
+constexpr size_t kSnapScaledTotal = kSnapScaled + sizeof(double) * EG_YEARS * 64;
+constexpr size_t kSnapPerm = kSnapScaledTotal + sizeof(double) * EG_YEARS;
+constexpr size_t kSnapMask = kSnapPerm + 64 * EG_YEARS;
 constexpr size_t kSnapDmask = kSnapMask + 8 * EG_YEARS;
 constexpr size_t kSnapOff = kSnapDmask + 8 * EG_YEARS;
 constexpr size_t kSnapOffd = kSnapOff + 4 * 28;
@@ -283,6 +288,22 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
     }
     std::memcpy(h + kSnapTotals, tot, sizeof(tot));
   }
+  if (s->iterations_without_improvement > 500u) {   // sampling.rs:190-220 on the un-nudged rows
+    const double stagnation = std::fmin(double(s->iterations_without_improvement) / 1000.0, 3.0);
+    const double power = 1.0 + (2.0 * stagnation);
+    double* scaled = reinterpret_cast<double*>(h + kSnapScaled);
+    double* totals = reinterpret_cast<double*>(h + kSnapScaledTotal);
+    uint8_t* perm = h + kSnapPerm;
+    for (int y = 0; y < EG_YEARS; ++y) {
+      const double* w = s->weights + y * EG_N_ACTIONS;
+      int order[EG_N_ACTIONS];
+      for (int a = 0; a < EG_N_ACTIONS; ++a) order[a] = a;
+      std::stable_sort(order, order + EG_N_ACTIONS, [&](int a, int b) { return w[a] > w[b]; });
+      double t = 0.0;
+      for (int i = 0; i < EG_N_ACTIONS; ++i) { scaled[y * 64 + i] = eg_detpow(w[order[i]], power); perm[y * 64 + i] = uint8_t(order[i]); t += scaled[y * 64 + i]; }
+      totals[y] = t;
+    }
+  }
   unsigned long long mask[26] = {0}, dmask[26] = {0};
   if (have_lists)
     for (int y = 0; y < EG_YEARS; ++y) {
@@ -298,6 +319,9 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   S.w = reinterpret_cast<const double*>(c->d_snap + kSnapW); S.dw = reinterpret_cast<const double*>(c->d_snap + kSnapDw);
   S.cw = s->count_weights ? reinterpret_cast<const double*>(c->d_snap + kSnapCw) : nullptr;
   S.row_totals = reinterpret_cast<const double*>(c->d_snap + kSnapTotals);
+  S.scaled = reinterpret_cast<const double*>(c->d_snap + kSnapScaled);
+  S.scaled_total = reinterpret_cast<const double*>(c->d_snap + kSnapScaledTotal);
+  S.scaled_perm = c->d_snap + kSnapPerm;
   S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
   S.has_best = s->has_best ? 1 : 0;
   // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)

@@ -79,6 +79,11 @@ struct DevSnapshot {
   const double* dw;   // [26][15]
   const double* cw;   // [26][21] or nullptr
   const double* row_totals;   // [26][3] table-order sums of the w / dw (first 14) / cw rows of each year (host-evaluated)
+  // stalled sampler (sampling.rs:190-220, stall > 500): per year the weights raised to the power in stable descending
+  // order, the permutation and the sum, evaluated on the host with the shared eg_detpow; valid until the first nudge
+  const double* scaled;       // [26][64]
+  const uint8_t* scaled_perm; // [26][64]
+  const double* scaled_total; // [26]
   double learning_rate, exploration_rate;
   uint32_t stall;
   int32_t has_best;

@@ -78,8 +78,8 @@ struct Rng {      // register part of the stream state; key / counter / buffer l
   unsigned int words;
 };
 struct Totals {   // sums of the weight rows in table order (sampling.rs:182, :352-355); recomputed only after a nudge
-  double main, deficit;
-  bool main_valid, deficit_valid;
+  double main, deficit, scaled;
+  bool main_valid, deficit_valid, scaled_valid;   // scaled_*: the stalled sampler's sorted / powered table in LDS
 };
 
 struct Agg {   // aggregates of the map at the current point of the year (map_handler.rs:819-965)
@@ -409,27 +409,35 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
   const double total = tot.main;
   if (total <= 0.0) return 3 * kPeaker;
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
-    const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
-    const double power = 1.0 + (2.0 * stagnation);
-    wave_sync();
-    if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
-      const double mine = sm.w[lane];
-      int rank = 0;
+    if (!tot.scaled_valid) {   // the row was nudged this year: rebuild the table (otherwise it is the host-built one)
+      const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
+      const double power = 1.0 + (2.0 * stagnation);
+      wave_sync();
+      if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
+        const double mine = sm.w[lane];
+        int rank = 0;
 #pragma unroll 4
-      for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
-      sm.scaled[rank] = eg_detpow(mine, power);
-      sm.ydef[128 + rank] = (uint8_t)lane;
+        for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
+        sm.scaled[rank] = eg_detpow(mine, power);
+        sm.ydef[128 + rank] = (uint8_t)lane;
+      }
+      wave_sync();
+      double total_scaled = 0.0;
+#pragma unroll 4
+      for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
+      tot.scaled = total_scaled; tot.scaled_valid = true;
     }
-    wave_sync();
-    double total_scaled = 0.0;
-#pragma unroll 4
-    for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
-    double v = rng_f64(r, lane) * total_scaled;
-    int pick = sm.ydef[128];
-#pragma unroll 4
-    for (int i = 0; i < EG_N_ACTIONS; ++i) { v -= sm.scaled[i]; if (v <= 0.0) { pick = sm.ydef[128 + i]; break; } }
-    wave_sync();
-    return pick;
+    double v = rng_f64(r, lane) * tot.scaled;
+    int idx = 0;                                  // the powered weights are > 0: count the entries still above zero
+    for (int i0 = 0; i0 < EG_N_ACTIONS; i0 += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u;
+        if (i < EG_N_ACTIONS) { v -= sm.scaled[i]; idx += v > 0.0 ? 1 : 0; }
+      }
+      if (!(v > 0.0)) break;
+    }
+    return sm.ydef[128 + (idx < EG_N_ACTIONS ? idx : 0)];
   }
   double v = rng_f64(r, lane) * total;
   // Every weight is >= MIN_WEIGHT > 0, so the running value only decreases: the entry at which it first reaches <= 0 is
@@ -583,6 +591,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
     if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
     if (lane < EG_N_COUNTS) sm.cw[lane] = ncw;
+    if (S.stall > 500u) { sm.scaled[lane] = S.scaled[yi * 64 + lane]; sm.ydef[128 + lane] = S.scaled_perm[yi * 64 + lane]; }
     if (yi + 1 < kYears) {
       if (lane < EG_N_ACTIONS) nw = S.w[(yi + 1) * EG_N_ACTIONS + lane];
       if (lane < EG_N_DEFICIT) ndw = S.dw[(yi + 1) * EG_N_DEFICIT + lane];
@@ -593,6 +602,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     }
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
     Totals tot; tot.main = S.row_totals[3 * yi]; tot.deficit = S.row_totals[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
+    tot.scaled = S.stall > 500u ? S.scaled_total[yi] : 0.0; tot.scaled_valid = true;
     const double cw_total = S.row_totals[3 * yi + 2];
 
     // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
@@ -805,7 +815,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
         update_deficit_weights(S, lane, action, combined);
         update_weights(S, lane, action, overall * 0.5);
-        tot.main_valid = false; tot.deficit_valid = false;
+        tot.main_valid = false; tot.deficit_valid = false; tot.scaled_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
         EG_T1(3);
       } else {            // simulation.rs:193-197
