@@ -226,17 +226,15 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// max over the 64 lanes of a non-negative double, returned in every lane.  DPP row shifts / row broadcasts move the two
-// dwords; each step keeps the lane's own value where a DPP source lane does not exist (old = self, bound_ctrl off), so
-// after the six steps lane 63 holds the maximum of all lanes.
-__device__ __forceinline__ double wave_max_f64(double v) {
-#define EG_DPP_MAX_STEP(ctrl, row_mask, bank_mask)                                                              \
-  {                                                                                                             \
-    const int lo = __double2loint(v), hi = __double2hiint(v);                                                   \
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, row_mask, bank_mask, false);                      \
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, row_mask, bank_mask, false);                      \
-    const double o = __hiloint2double(ohi, olo);                                                                \
-    v = o > v ? o : v;                                                                                          \
+// max over the 64 lanes of a NON-NEGATIVE double, returned in every lane.  For non-negative IEEE doubles the order of the
+// values is the order of their bit patterns, so the maximum is found on the high dwords first and then on the low dwords
+// of the lanes that hold that high dword: two 32-bit DPP reductions (row shifts / row broadcasts; a lane without a DPP
+// source reads 0, the identity of an unsigned max) instead of one on 64-bit pairs.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define EG_DPP_MAX_STEP(ctrl, row_mask, bank_mask)                                                      \
+  {                                                                                                     \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, bank_mask, false); \
+    v = o > v ? o : v;                                                                                  \
   }
   EG_DPP_MAX_STEP(0x111, 0xf, 0xf)   // row_shr:1
   EG_DPP_MAX_STEP(0x112, 0xf, 0xf)   // row_shr:2
@@ -246,18 +244,25 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   EG_DPP_MAX_STEP(0x142, 0xa, 0xf)   // row_bcast:15 row_mask:0xa
   EG_DPP_MAX_STEP(0x143, 0xc, 0xf)   // row_bcast:31 row_mask:0xc
 #undef EG_DPP_MAX_STEP
-  return readlane_f64(v, 63);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+  const unsigned hi = (unsigned)__double2hiint(v);
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned ml = wave_max_u32(hi == mh ? (unsigned)__double2loint(v) : 0u);
+  return __hiloint2double((int)mh, (int)ml);
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
-// index into the 13x13 factor table of a radius class: min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)
-__device__ __forceinline__ int penalty_index(short2v cpk, int gen_packed) {
+// byte offset into the 13x13 factor table of a radius class: (min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)) * 8,
+// packed 16-bit arithmetic and one dot product
+__device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
   short2v d = cpk - g;
-  const short2v zero = {0, 0}, cap = {12, 12};
-  d = __builtin_elementwise_max(d, zero - d);
+  const short2v cap = {12, 12}, stride = {13 * 8, 8};
+  d = __builtin_elementwise_max(d, g - cpk);
   d = __builtin_elementwise_min(d, cap);
-  return (int)d.x * 13 + (int)d.y;
+  return __builtin_amdgcn_sdot2(d, stride, 0, false);
 }
 
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
@@ -289,23 +294,27 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     const int ci = cell_cur / kGrid, cj = cell_cur - ci * kGrid;
     double s = te_cur;
     const short2v cpk = {(short)ci, (short)cj};
+    const char* drb = reinterpret_cast<const char*>(dr);
     for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
-      const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : 0;
+      // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
+      const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
       const int mi = mine / kGrid;
-      const int mp = mi | ((mine - mi * kGrid) << 16);               // (gi, gj) as two int16: one readlane per generator
+      const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
       const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
       // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
-      // exactly, so out-of-range generators multiply by 1.0 instead of branching.  (|di|, |dj|) are computed with
-      // packed 16-bit ops and turned into the table index by one dot product.  Four generators per trip: their index
-      // arithmetic and LDS reads are independent, only the four multiplies form a chain.
-      int j = 0;
-      for (; j + 4 <= cnt; j += 4) {
-        double f[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = dr[penalty_index(cpk, __builtin_amdgcn_readlane(mp, j + u))];
-        s = s * f[0]; s = s * f[1]; s = s * f[2]; s = s * f[3];
+      // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
+      // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
+      // current four are multiplied in list order (only the multiplies form a chain).
+#define EG_FACTOR(j) (*reinterpret_cast<const double*>(drb + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)))))
+      double f0 = EG_FACTOR(0), f1 = EG_FACTOR(1), f2 = EG_FACTOR(2), f3 = EG_FACTOR(3);
+      for (int j = 4; j < cnt; j += 4) {
+        const double g0 = EG_FACTOR(j), g1 = EG_FACTOR(j + 1), g2 = EG_FACTOR(j + 2), g3 = EG_FACTOR(j + 3);
+        __builtin_amdgcn_sched_barrier(0);      // keep the four LDS reads in flight ahead of the multiply chain
+        s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+        f0 = g0; f1 = g1; f2 = g2; f3 = g3;
       }
-      for (; j < cnt; ++j) s = s * dr[penalty_index(cpk, __builtin_amdgcn_readlane(mp, j))];
+      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+#undef EG_FACTOR
     }
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
@@ -544,11 +553,19 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 }
 
 #ifdef EG_STAMPS
-#define EG_T0() const unsigned long long t0_ = __builtin_readcyclecounter()
-#define EG_T1(slot) stamps[slot] += __builtin_readcyclecounter() - t0_
+// every cycle of the episode is attributed: a mark charges the time since the previous mark to `slot`
+#define EG_MARK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); stamps[slot] += now_ - last_; last_ = now_; } while (0)
+#define EG_MARKG(slot) EG_MARK(slot)
+#define EG_T0() EG_MARK(6)
+#define EG_T1(slot) EG_MARK(slot)
+#define EG_TB(slot) EG_MARK(6)
+#define EG_TE(slot) EG_MARK(slot)
 #else
 #define EG_T0() do {} while (0)
 #define EG_T1(slot) do {} while (0)
+#define EG_TB(slot) do {} while (0)
+#define EG_MARKG(slot) do {} while (0)
+#define EG_TE(slot) do {} while (0)
 #endif
 
 __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
@@ -560,13 +577,15 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
   const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
-  unsigned long long stamps[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamps[32] = {};
   const unsigned long long t_begin = __builtin_readcyclecounter();
+  unsigned long long last_ = t_begin;
 #endif
 
   load_static_tables(T, lane);
   Rng rng;
   rng_seed(rng, seed + first_index + (unsigned long long)e, lane);   // simulation.rs:50-53, one stream per episode
+  EG_MARKG(16);
 
   Episode ep;
   ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32.0;
@@ -586,7 +605,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
     {  // this year's policy rows -> LDS (they were requested a year ahead: nw / ndw / ncw), then request next year's
-    EG_T0();
+    EG_MARKG(17);
     wave_sync();
     if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
     if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
@@ -600,10 +619,12 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     wave_sync();
     EG_T1(5);
     }
+    EG_MARKG(18);
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
     Totals tot; tot.main = S.row_totals[3 * yi]; tot.deficit = S.row_totals[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
     tot.scaled = S.stall > 500u ? S.scaled_total[yi] : 0.0; tot.scaled_valid = true;
     const double cw_total = S.row_totals[3 * yi + 2];
+    EG_TE(14);
 
     // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
     //      The lanes gather the per-generator terms in parallel; the sums are then folded lane by lane (readlane),
@@ -615,7 +636,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
     a.optot = sm.yr[4][yi]; a.opcnt = sm.yr_opcnt[yi];
     {
-      EG_T0();
+      EG_MARKG(18);
       const double pco2 = sm.yr[0][yi], ptg = sm.yr[1][yi], pig = sm.yr[2][yi], psg = sm.yr[3][yi];
       const bool carry = yi > 0 && pco2 == sm.yr[0][yi - 1] && ptg == sm.yr[1][yi - 1] && pig == sm.yr[2][yi - 1] && psg == sm.yr[3][yi - 1];
       if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
@@ -670,6 +691,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
 
     // ---- the year's actions: phase 0 = deficit repair (simulation.rs:137-141, :319-522),
     //      phase 1 = additional actions (simulation.rs:144-198).  One loop so that apply_action is emitted once. ----
+    EG_MARKG(18);
     int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
     const State year_start = state_of(a);
     int phase = year_start.balance < 0.0 ? 0 : 1;
@@ -678,6 +700,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     uint32_t attempts = 0, n_add = 0, k_add = 0;
     bool n_add_known = false;
     State cur = year_start;
+    EG_TE(15);
 
     for (int guard = 0; guard < 200000 && ep.status == EG_EP_OK; ++guard) {
       int action;
@@ -695,7 +718,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
           continue;
         }
         attempts += 1;
-        EG_T0();
+        EG_MARKG(19);
         if (attempts < 5u) {
           if (replay) {   // sampling.rs:242-313
             const int lo = S.bestd_off[yi], n = S.bestd_off[yi + 1] - lo;
@@ -712,7 +735,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
       } else {
         if (!n_add_known) {   // simulation.rs:144-187
           n_add_known = true;
-          EG_T0();
+          EG_MARKG(24);
           if (replay) {
             n_add = S.has_best_actions ? (uint32_t)(S.best_off[yi + 1] - S.best_off[yi]) : 0u;
           } else {   // sampling.rs:380-443
@@ -740,7 +763,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         }
         if (k_add >= n_add) break;
         k_add += 1;
-        EG_T0();
+        EG_MARKG(19);
         if (replay) {   // sampling.rs:78-145
           const int lo = S.best_off[yi], n = S.best_off[yi + 1] - lo;
           if (S.has_best_actions && replay_idx < n) { action = S.best_actions[lo + replay_idx]; replay_idx += 1; }
@@ -760,7 +783,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         const double2 ccv = *reinterpret_cast<const double2*>(T.cc + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
         const double cc_prev = yi > 0 ? T.cc[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
         const double t12v = T.t12[(size_t)yi * kTypes + t];
-        EG_T0();
+        EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
         const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, &m03v, stamps);
@@ -771,6 +794,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
+        EG_MARKG(21);
         if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) {
           sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
@@ -788,7 +812,9 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
+        EG_TE(12);
       } else if (action < kFirstOther) {
+        EG_MARKG(20);
         const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
         if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; break; }
         const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9));
@@ -798,6 +824,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         a.offs += T.offv[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
         a.ocost += T.offc[((size_t)yi * kOffsetTypes + ot) * kMults + m];
         if (yi > 0) a.ocost_prev += T.offc[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
+        EG_TE(13);
       }
       // 57..59 carry an empty generator id (core.rs:117-119): the lookup fails, nothing changes.  60: DoNothing.
 
@@ -805,7 +832,7 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128 || ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; run_log[ep.run_pos] = (uint8_t)action; }
         ep.def_pos += 1; ep.n_def_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
-        EG_T0();
+        EG_MARKG(22);
         const State nxt = state_of(a);
         const double overall = evaluate_impact(cur, nxt);
         const double em = nxt.net < cur.net ? (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0) : 0.0;
@@ -822,13 +849,14 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         if (ep.act_pos >= EG_ACT_CAP || ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) { act_log[ep.act_pos] = (uint8_t)action; run_log[ep.run_pos] = (uint8_t)action; }
         ep.act_pos += 1; ep.n_act_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
+        EG_MARKG(23);
       }
     }
     if (ep.status != EG_EP_OK) break;
     ep.bytes += 2.0 * (double)(ep.n_act_y + ep.n_def_y);
 
     // ---- yearly metrics (metrics_calculation.rs:32-175) ----
-    EG_T0();
+    EG_MARKG(25);
     const State s = state_of(a);
     const double gen = (a.tg + a.ig) + a.sg;
     const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * sm.yr[8][yi];
@@ -878,10 +906,11 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     O.n_draws[e] = (unsigned long long)rng.words;
     O.bytes_moved[e] = ep.bytes;
 #ifdef EG_STAMPS
+    EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
     // diagnostic build only: cycle shares go to the (otherwise unread) tail of this episode's act_log buffer
-    unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 128);
-    for (int i = 0; i < 16; ++i) dbg[i] = stamps[i];
+    unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 256);
+    for (int i = 0; i < 32; ++i) dbg[i] = stamps[i];
 #endif
   }
   if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes

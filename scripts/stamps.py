@@ -1,6 +1,6 @@
 """Diagnostic: where does an episode spend its cycles?  Needs the -DEG_STAMPS build (make -C eirgrid_amd/csrc stamps):
    EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/stamps.py
-Shares only; never quote this build's run time."""
+Every cycle of an episode is charged to exactly one slot.  Shares only; never quote this build's run time."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,17 +8,22 @@ from eirgrid_amd import synthetic_world
 from eirgrid_amd.engine import ActionWeights, Engine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 eng = Engine(synthetic_world()); pol = ActionWeights()
-eng.upload_snapshot(pol); eng.launch(12345, 0, B); eng.sync()
+eng.upload_snapshot(pol, write_yearly=(os.environ.get('EG_NO_YEARLY') is None)); eng.launch(12345, 0, B); eng.sync()
 res = eng.fetch(B)
-st = res.act_log[:, -128:].copy().view(np.uint64).astype(np.float64)   # [B, 16]
-names = ["year-start aggregates", "placement search", "sampling (rng + walks)", "deficit evaluate + nudges", "yearly metrics + stores", "-", "-", "episode total"]
+st = res.act_log[:, -256:].copy().view(np.uint64).astype(np.float64)   # [B, 32]
+names = {0: "year-start aggregates", 1: "placement search", 2: "sampling (rng + walks)", 3: "deficit evaluate + nudges",
+         4: "yearly metrics + stores", 5: "policy rows -> LDS", 6: "glue (unnamed)", 12: "apply: generator bookkeeping",
+         13: "apply: offset", 14: "year: totals scalars", 15: "year: initial state", 16: "episode start (tables, seed)",
+         17: "glue: year loop back edge", 18: "glue: before aggregates", 19: "glue: loop top -> sampling",
+         20: "glue: sampled -> search/offset", 21: "glue: search -> bookkeeping", 22: "glue: apply -> evaluate (logs)",
+         23: "phase-1 logs + back edge", 24: "glue: before n_add", 25: "glue: loop exit -> metrics", 26: "episode end"}
 tot = st[:, 7].mean()
 print(f"B={B}  mean episode cycles {tot:.0f}  (min {st[:,7].min():.0f} max {st[:,7].max():.0f})  gens/ep {res.n_gens.mean():.1f}")
-for i, n in enumerate(names[:5]):
-    print(f"  {n:28s} {st[:, i].mean():10.0f} cycles  {100 * st[:, i].mean() / tot:5.1f} %")
-print(f"  {'policy rows -> LDS':28s} {st[:, 5].mean():10.0f} cycles  {100 * st[:, 5].mean() / tot:5.1f} %")
-acc = st[:, :6].sum(1).mean()
-print(f"  {'unaccounted':28s} {tot - acc:10.0f} cycles  {100 * (tot - acc) / tot:5.1f} %")
+acc = 0.0
+for i, n in names.items():
+    v = st[:, i].mean(); acc += v
+    print(f"  {n:34s} {v:10.0f} cycles  {100 * v / tot:5.1f} %")
+print(f"  {'unattributed':34s} {tot - acc:10.0f} cycles  {100 * (tot - acc) / tot:5.1f} %")
 print(f"  placement detail: searches/ep {st[:, 11].mean():.1f}  chunks/search {st[:, 8].sum() / st[:, 11].sum():.2f}  "
       f"generator loop {st[:, 9].mean():.0f} cyc/ep ({st[:, 9].sum() / st[:, 8].sum():.0f}/chunk)  reduce+select {st[:, 10].mean():.0f} cyc/ep ({st[:, 10].sum() / st[:, 8].sum():.0f}/chunk)  "
       f"rest (loads, setup, exit test) {(st[:, 1] - st[:, 9] - st[:, 10]).mean():.0f} cyc/ep")

@@ -190,3 +190,36 @@ def test_unsupported_inputs_fail_loudly(engine):
     pol = ActionWeights()
     with pytest.raises(N.EirgridError):
         engine.rollout_batch(pol, 1, 4, enable_construction_delays=True)
+
+
+def test_fuzzed_snapshots_and_replay_fallbacks(engine, world):
+    """Randomised policies: perturbed tables, random stall / rates, and replay against RANDOM best lists (any of the 61
+    actions, wrong lengths) so that non-generator deficit replays, the 20-action overshoot of Q15 and the smart fallbacks
+    (sampling.rs:445-528, next_u32 draws) are exercised.  Every episode bit-identical to the tabled oracle."""
+    tb = _tabled(world)
+    rng = np.random.default_rng(2024)
+    for trial in range(6):
+        pol = ActionWeights()
+        # a synthetic "best strategy": random lists, sometimes empty years, sometimes long
+        run = [rng.integers(0, 61, int(rng.choice([0, 0, 1, 2, 5, 12]))).tolist() for _ in range(26)]
+        dfl = [(3 * rng.choice([8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14], int(rng.choice([0, 1, 2, 3])))).tolist() for _ in range(26)]
+        if trial >= 2:
+            dfl[0] = rng.integers(0, 61, 3).tolist()          # includes non-generator actions: skipped by the repair loop
+        nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
+        metrics = [float(rng.choice([-5e4, 3e5])), 0.7, float(rng.choice([4e10, 9e11])), 1.0]
+        pol.apply_episode(metrics, nr, np.array([a for l in run for a in l], np.uint8), nd, np.array([a for l in dfl for a in l], np.uint8))
+        assert pol.get("has_best_actions") == 1
+        w, dw, cw = pol.tables()
+        pol.set_tables(np.clip(w * 10 ** rng.uniform(-1.5, 1.0, w.shape), 1e-4, 0.999),
+                       np.clip(dw * 10 ** rng.uniform(-1.5, 1.0, dw.shape), 1e-4, 0.999), cw * rng.uniform(0.2, 3.0, cw.shape))
+        pol.set("iterations_without_improvement", int(rng.choice([0, 50, 150, 480, 520, 1400, 4000])))
+        pol.set("learning_rate", float(rng.uniform(0.05, 0.5))); pol.set("exploration_rate", float(rng.uniform(0.0, 0.9)))
+        if trial % 2 == 1:
+            pol.set("has_count_weights", 0)
+        n = 96
+        mask = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+        res = engine.rollout_batch(pol, 31337 + trial, n, first_episode_index=100 * trial, replay_mask=mask)
+        for e in range(n):
+            st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 31337 + trial + 100 * trial + e, replay=bool(mask[e]))
+            assert_episode_equal(res, e, ref, f"fuzz {trial}")
+        assert (res.n_draws[mask == 1] > 0).any(), "some replay episode must have fallen back to seeded draws"

@@ -84,3 +84,24 @@ def test_tables_stalled_and_best_state(world):
     _check(world, [31, 32], tweak=lambda w: w.set_has_count_weights(0))
     for stall in (600, 2500):      # power-scaled sampler
         _check(world, [41, 42], tweak=lambda w, s=stall: w.set("stall", s))
+
+
+def test_tables_fuzzed_replay_fallbacks(world):
+    """Literal vs tabled oracle on replay episodes whose best lists are random (fallback samplers, non-generator repairs)."""
+    rng = np.random.default_rng(7)
+    ow = O.OracleWorld(world)
+    ot = O.OracleTables(HostTables(world), len(world.existing_x))
+    for trial in range(4):
+        run = [rng.integers(0, 61, int(rng.choice([0, 1, 3, 9]))).tolist() for _ in range(26)]
+        dfl = [rng.integers(0, 61, int(rng.choice([0, 1, 2]))).tolist() for _ in range(26)]
+        outs = []
+        for mode in (0, 1):
+            w = O.OracleWeights()
+            w.set("has_best", 1); w.set("has_best_actions", 1); w.set("has_best_deficit_actions", 1); w.set("stall", 30 * trial)
+            for y in range(26):
+                w.set_list(0, y, run[y]); w.set_list(1, y, dfl[y])
+            st, out = (O.run_episode(ow, w, 555 + trial, replay=True) if mode == 0 else O.run_episode_tabled(ot, w, 555 + trial, replay=True))
+            assert st == 0
+            outs.append(out)
+        assert _same(*outs), f"trial {trial}"
+        assert outs[0].n_draws > 0
