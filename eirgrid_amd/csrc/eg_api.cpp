@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,8 @@ struct eg_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double total_ms = 0.0; int32_t n_launches = 0;
   bool timing_pending = false;
+  // batches of at most this many episodes run the helper-wave kernel (three waves per episode, all resident at once)
+  uint32_t helper_max_episodes = 0;
 };
 
 namespace {
@@ -166,6 +169,17 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   if (device_ordinal < 0 || device_ordinal >= n) { set_error("eg_create: device ordinal out of range"); return nullptr; }
   if (hipSetDevice(device_ordinal) != hipSuccess) { set_error("eg_create: hipSetDevice failed"); return nullptr; }
   eg_ctx* c = new eg_ctx();
+  {
+    // The small-batch kernel holds 3 waves per episode at 3 waves per SIMD: 4 episodes per CU are resident together.
+    // EIRGRID_HELPER_WAVES=0 disables it, =all uses it for every batch size (diagnostics / parity tests).
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess) cus = 0;
+    c->helper_max_episodes = 4u * (uint32_t)(cus > 0 ? cus : 0);
+    if (const char* hv = std::getenv("EIRGRID_HELPER_WAVES")) {
+      if (std::string(hv) == "0") c->helper_max_episodes = 0;
+      else if (std::string(hv) == "all") c->helper_max_episodes = 0xFFFFFFFFu;
+    }
+  }
   c->device = device_ordinal;
   build_tables(*world, c->tables.H);
   c->tables.index();
@@ -368,7 +382,7 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
   EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, nullptr, nullptr);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, nullptr, nullptr, n <= c->helper_max_episodes);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
@@ -391,7 +405,7 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
   EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, (long long*)d_packet, nullptr);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, (long long*)d_packet, nullptr, n <= c->helper_max_episodes);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;

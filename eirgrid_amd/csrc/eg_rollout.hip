@@ -27,6 +27,7 @@ namespace eg {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kHelperWaves = 2;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
 constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
 constexpr double kMaxWeight = 0.999;    // constants.rs:15
 constexpr double kMaxCost = 50000000000.0;   // config/constants.rs:115
@@ -58,6 +59,10 @@ struct __align__(16) Smem {
   uint8_t gbm[EG_MAX_GENS];           // build-year index | mult << 5
   uint8_t ydef[192];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
                                       // [128,192) sort permutation of the stalled sampler
+  // helper waves (small-batch kernel only): search command (double-buffered by sequence parity), results, flags
+  int cmd[2][2];                      // {year | variant << 8 | radius class << 12 (or -1: exit), generators in the list}
+  uint32_t hflag[2];                  // sequence number of the search whose result is in hres[h]
+  struct { double score, m03; int cell, pad; } hres[2];
 };
 static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
 
@@ -265,8 +270,90 @@ __device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed) {
   return __builtin_amdgcn_sdot2(d, stride, 0, false);
 }
 
+// Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
+__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
+                                              double cf, int cell) {
+  const int ci = cell / kGrid, cj = cell - ci * kGrid;
+  double s = te;
+  const short2v cpk = {(short)ci, (short)cj};
+  const char* drb = reinterpret_cast<const char*>(dr);
+  for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
+    // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
+    const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
+    const int mi = mine / kGrid;
+    const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
+    const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+    // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
+    // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
+    // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
+    // current four are multiplied in list order (only the multiplies form a chain).
+#define EG_FACTOR(j) (*reinterpret_cast<const double*>(drb + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)))))
+    double f0 = EG_FACTOR(0), f1 = EG_FACTOR(1), f2 = EG_FACTOR(2), f3 = EG_FACTOR(3);
+    for (int j = 4; j < cnt; j += 4) {
+      const double g0 = EG_FACTOR(j), g1 = EG_FACTOR(j + 1), g2 = EG_FACTOR(j + 2), g3 = EG_FACTOR(j + 3);
+      __builtin_amdgcn_sched_barrier(0);      // keep the four LDS reads in flight ahead of the multiply chain
+      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+      f0 = g0; f1 = g1; f2 = g2; f3 = g3;
+    }
+    s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+#undef EG_FACTOR
+  }
+  s = (s * cf) * size_factor;
+  return r < kCells ? s : 0.0;
+}
+
+struct ChunkBest { double score, m03; int cell; };
+// maximum of a chunk's scores, ties to the lowest cell, with the winner's 0.03 * mean settlement opinion
+__device__ __forceinline__ ChunkBest chunk_reduce(double s, int cell, double m03) {
+  ChunkBest b;
+  b.score = wave_max_f64(s);
+  int win_c = s == b.score ? cell : kCells;
+  const unsigned long long holders = __ballot(s == b.score);
+  if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell, __ffsll((long long)holders) - 1);
+  else {
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) { const int other = __shfl_xor(win_c, sh); win_c = other < win_c ? other : win_c; }
+  }
+  b.cell = win_c;
+  const unsigned long long owner = __ballot(s == b.score && cell == win_c);   // the lane that holds the winner
+  b.m03 = readlane_f64(m03, __ffsll((long long)owner) - 1);
+  return b;
+}
+
+// Workgroup barrier that orders LDS only: the episode's output stores and table loads stay in flight across it.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Helper waves (kHelpers > 0, small batches only).  At B <= 4 x CUs every SIMD holds a single episode wave that is
+// latency-bound, and a launch lasts as long as its slowest episode, whose time is dominated by placement searches that
+// need several chunks.  Two more waves per episode evaluate chunks 1 and 2 of every search while the episode wave
+// evaluates chunk 0; the episode wave merges their maxima in chunk order with the same tie rule, so the winner is the
+// one the sequential scan finds (a chunk the sequential scan would not have reached only holds candidates whose
+// unpenalised score is already below the best, so evaluating it changes nothing).
+//   protocol: episode wave writes cmd[seq & 1] and meets the helpers at a barrier; helper h evaluates chunk h and
+//   publishes {result, flag = seq}; the episode wave reads a helper's result only if that chunk's bound still reaches
+//   the best score, after spinning on its flag.  The next barrier cannot complete before every helper is back.
+__device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h) {
+  const double size_factor = T.size_factor;
+  for (uint32_t sq = 1;; ++sq) {
+    wg_barrier_lds();
+    const int c0 = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][0]);
+    const int ngen_s = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][1]);
+    if (c0 < 0) return;
+    const int yi = c0 & 31, v = (c0 >> 8) & 15, rc = (c0 >> 12) & 15;
+    const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
+    const int r = h * kWave + lane;
+    const double te = T.ps_te[o + r], cf = T.ps_cf[o + r], m03 = T.ps_m03[o + r]; const int cell = T.ps_cell[o + r];
+    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, te, cf, cell);
+    const ChunkBest b = chunk_reduce(s, cell, m03);
+    if (lane == 0) { sm.hres[h - 1].score = b.score; sm.hres[h - 1].m03 = b.m03; sm.hres[h - 1].cell = b.cell; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *(volatile uint32_t*)&sm.hflag[h - 1] = sq;
+  }
+}
+
+template <int kHelpers>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
-                                            double* best_m03, unsigned long long* stamps = nullptr) {
+                                            double* best_m03, uint32_t* seq = nullptr, unsigned long long* stamps = nullptr) {
   const int info = sm.type_info[type];
   const int v = info & 15, rc = (info >> 4) & 15;
   const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
@@ -279,9 +366,47 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double best = 0.0, m03w = 0.0; int best_c = kCells;
+  int first = 0;
+  bool more = true;
   // chunk 0 is loaded here, chunk k+1 while chunk k is being evaluated
   double te = tes[lane], cf = cfs[lane], m03 = m03s[lane]; int cell = cells[lane];
-  for (int chunk = 0; chunk < kChunks; ++chunk) {
+  if constexpr (kHelpers > 0) {
+    // lanes 0..kHelpers: unpenalised score of the first candidate of chunks 1..kHelpers+1 = the bound of that chunk
+    const int bl = (lane <= kHelpers ? lane + 1 : 1) * kWave;
+    const double bound = (tes[bl] * cfs[bl]) * size_factor;
+    *seq += 1;
+    const uint32_t sq = *seq;
+    if (lane == 0) { sm.cmd[sq & 1][0] = yi | (v << 8) | (rc << 12); sm.cmd[sq & 1][1] = ngen_s; }
+    wg_barrier_lds();
+#ifdef EG_STAMPS
+    if (stamps) stamps[8] += 1;
+    const unsigned long long tg0 = __builtin_readcyclecounter();
+#endif
+    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, te, cf, cell);
+#ifdef EG_STAMPS
+    const unsigned long long tg1 = __builtin_readcyclecounter();
+    if (stamps) stamps[9] += tg1 - tg0;
+#endif
+    const ChunkBest b0 = chunk_reduce(s0, cell, m03);
+    if (b0.score > 0.0) { best = b0.score; best_c = b0.cell; m03w = b0.m03; }
+    for (int h = 1; h <= kHelpers && more; ++h) {
+      if (!(readlane_f64(bound, h - 1) >= best)) { more = false; break; }
+      while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[h - 1]) != (int)sq) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      const double hs = sm.hres[h - 1].score; const int hc = sm.hres[h - 1].cell;
+      if (hs > best || (hs == best && hs > 0.0 && hc < best_c)) { best = hs; best_c = hc; m03w = sm.hres[h - 1].m03; }
+#ifdef EG_STAMPS
+      if (stamps) stamps[8] += 1;
+#endif
+    }
+    if (more && !(readlane_f64(bound, kHelpers) >= best)) more = false;
+    first = kHelpers + 1;
+    if (more) { const int r = first * kWave + lane; te = tes[r]; cf = cfs[r]; m03 = m03s[r]; cell = cells[r]; }
+#ifdef EG_STAMPS
+    if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
+#endif
+  }
+  for (int chunk = first; more && chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
     const double base = (te * cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
     if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
@@ -291,51 +416,14 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-    const int ci = cell_cur / kGrid, cj = cell_cur - ci * kGrid;
-    double s = te_cur;
-    const short2v cpk = {(short)ci, (short)cj};
-    const char* drb = reinterpret_cast<const char*>(dr);
-    for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
-      // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
-      const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
-      const int mi = mine / kGrid;
-      const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
-      const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-      // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
-      // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
-      // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
-      // current four are multiplied in list order (only the multiplies form a chain).
-#define EG_FACTOR(j) (*reinterpret_cast<const double*>(drb + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)))))
-      double f0 = EG_FACTOR(0), f1 = EG_FACTOR(1), f2 = EG_FACTOR(2), f3 = EG_FACTOR(3);
-      for (int j = 4; j < cnt; j += 4) {
-        const double g0 = EG_FACTOR(j), g1 = EG_FACTOR(j + 1), g2 = EG_FACTOR(j + 2), g3 = EG_FACTOR(j + 3);
-        __builtin_amdgcn_sched_barrier(0);      // keep the four LDS reads in flight ahead of the multiply chain
-        s = s * f0; s = s * f1; s = s * f2; s = s * f3;
-        f0 = g0; f1 = g1; f2 = g2; f3 = g3;
-      }
-      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
-#undef EG_FACTOR
-    }
+    const double s = chunk_score(dr, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
 #endif
-    s = (s * cf_cur) * size_factor;
-    if (r >= kCells) s = 0.0;
     if (__any(s > best || (s == best && s > 0.0 && cell_cur < best_c))) {
-      const double wmax = wave_max_f64(s);
-      int win_c = s == wmax ? cell_cur : kCells;
-      const unsigned long long holders = __ballot(s == wmax);
-      if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell_cur, __ffsll((long long)holders) - 1);
-      else {
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) { const int other = __shfl_xor(win_c, sh); win_c = other < win_c ? other : win_c; }
-      }
-      if (wmax > best || (wmax == best && win_c < best_c)) {
-        best = wmax; best_c = win_c;
-        const unsigned long long owner = __ballot(s == wmax && cell_cur == win_c);   // the lane that holds the winner
-        m03w = readlane_f64(m03_cur, __ffsll((long long)owner) - 1);
-      }
+      const ChunkBest b = chunk_reduce(s, cell_cur, m03_cur);
+      if (b.score > best || (b.score == best && b.cell < best_c)) { best = b.score; best_c = b.cell; m03w = b.m03; }
     }
 #ifdef EG_STAMPS
     if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
@@ -568,12 +656,18 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 #define EG_TE(slot) do {} while (0)
 #endif
 
-__global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
-                                                   unsigned long long first_index, uint32_t n_episodes,
-                                                   const uint8_t* __restrict__ replay_mask, StatsParams P, long long* stats) {
-  const int lane = threadIdx.x;
+template <int kHelpers>
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
+                                                                    unsigned long long first_index, uint32_t n_episodes,
+                                                                    const uint8_t* __restrict__ replay_mask, StatsParams P, long long* stats) {
+  const int lane = threadIdx.x & (kWave - 1);
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
+  uint32_t search_seq = 0;
+  if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave > 0) { helper_loop(T, lane, wave); return; }
+  }
   const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
@@ -786,11 +880,11 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
-        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, &m03v, stamps);
+        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, &search_seq, stamps);
         stamps[11] += 1;
 #else
         double m03v = 0.0;
-        const int cell = place_search(T, lane, yi, t, ep.ngen, nullptr, &m03v);
+        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, &search_seq);
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
@@ -913,9 +1007,14 @@ __global__ void __launch_bounds__(kWave, 3) k_rollout(DevTables T, DevSnapshot S
     for (int i = 0; i < 32; ++i) dbg[i] = stamps[i];
 #endif
   }
+  if constexpr (kHelpers > 0) {   // release the helper waves
+    search_seq += 1;
+    if (lane == 0) sm.cmd[search_seq & 1][0] = -1;
+    wg_barrier_lds();
+  }
   if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes
     __threadfence();
-    __syncthreads();
+    wave_sync();
     episode_update_stats(O, S, P, e, lane, stats);
   }
 }
@@ -928,7 +1027,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   load_static_tables(T, lane);
   __syncthreads();
   double score = 0.0;
-  const int cell = place_search(T, lane, yi, type, n_extra, &score, nullptr);
+  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr);
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
@@ -971,10 +1070,15 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
 }  // namespace
 
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream) {
+                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream,
+                   bool helper_waves) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_rollout, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
-                     (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
+  if (helper_waves)
+    hipLaunchKernelGGL(k_rollout<kHelperWaves>, dim3(n), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream, t, s, o,
+                       (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
+  else
+    hipLaunchKernelGGL(k_rollout<0>, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
+                       (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,

@@ -223,3 +223,38 @@ def test_fuzzed_snapshots_and_replay_fallbacks(engine, world):
             st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 31337 + trial + 100 * trial + e, replay=bool(mask[e]))
             assert_episode_equal(res, e, ref, f"fuzz {trial}")
         assert (res.n_draws[mask == 1] > 0).any(), "some replay episode must have fallen back to seeded draws"
+
+
+def test_helper_wave_kernel_equals_single_wave_kernel(world):
+    """Small batches run three waves per episode (two helper waves evaluate chunks 1 and 2 of every placement search);
+    large batches run one.  Both kernels, forced through the same 1,536 episodes (fresh and stalled policy, with
+    replays), must agree on every output byte — and a sample of them with the tabled oracle."""
+    tb = _tabled(world)
+    engines = {}
+    for mode in ("0", "all"):
+        os.environ["EIRGRID_HELPER_WAVES"] = mode
+        try:
+            engines[mode] = Engine(world, device=0)
+        finally:
+            del os.environ["EIRGRID_HELPER_WAVES"]
+    try:
+        for stall in (0, 1200):
+            pol = ActionWeights()
+            pol.set("iterations_without_improvement", stall)
+            n = 1536
+            mask = (np.arange(n) % 7 == 3).astype(np.uint8)
+            a = engines["0"].rollout_batch(pol, 2468, n, first_episode_index=77, replay_mask=mask)
+            b = engines["all"].rollout_batch(pol, 2468, n, first_episode_index=77, replay_mask=mask)
+            assert (a.status == 0).all()
+            for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
+                assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
+            for e in range(n):
+                g = int(a.n_gens[e])
+                assert a.gen_cell[e, :g].tobytes() == b.gen_cell[e, :g].tobytes() and a.gen_pack[e, :g].tobytes() == b.gen_pack[e, :g].tobytes()
+                assert a.lists(e, "run") == b.lists(e, "run") and a.lists(e, "def") == b.lists(e, "def") and a.lists(e, "act") == b.lists(e, "act")
+            for e in range(0, n, 97):
+                st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 2468 + 77 + e, replay=bool(mask[e]))
+                assert_episode_equal(b, e, ref, f"helper kernel, stall {stall}")
+    finally:
+        for eng in engines.values():
+            eng.close()
