@@ -75,32 +75,10 @@ struct eg_ctx {
 
 namespace {
 
-// byte offsets inside the packed snapshot buffer
-constexpr size_t kSnapW = 0;
-constexpr size_t kSnapDw = kSnapW + sizeof(double) * EG_YEARS * EG_N_ACTIONS;
-constexpr size_t kSnapCw = kSnapDw + sizeof(double) * EG_YEARS * EG_N_DEFICIT;
-constexpr size_t kSnapTotals = kSnapCw + sizeof(double) * EG_YEARS * EG_N_COUNTS;
-constexpr size_t kSnapScaled = kSnapTotals + sizeof(double) * EG_YEARS * 3;
-constexpr size_t kSnapScaledTotal = kSnapScaled + sizeof(double) * EG_YEARS * 64;
-constexpr size_t kSnapPerm = kSnapScaledTotal + sizeof(double) * EG_YEARS;
-constexpr size_t kSnapMask = kSnapPerm + 64 * EG_YEARS;
-constexpr size_t kSnapDmask = kSnapMask + 8 * EG_YEARS;
-constexpr size_t kSnapOff = kSnapDmask + 8 * EG_YEARS;
-constexpr size_t kSnapOffd = kSnapOff + 4 * 28;
-constexpr size_t kSnapBest = kSnapOffd + 4 * 28;
-constexpr size_t kSnapBestCap = 4096;     // best_actions can hold every replay-doubled year list
-constexpr size_t kSnapBestd = kSnapBest + kSnapBestCap;
-constexpr size_t kSnapBytes = kSnapBestd + kSnapBestCap;
-
 template <typename T>
-int upload_vec(eg_ctx* c, const std::vector<T>& v, const T** dst) {
-  void* p = nullptr;
-  size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
-  EG_HIP(hipMalloc(&p, bytes));
-  c->allocs.push_back(p);
-  if (!v.empty()) EG_HIP(hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-  *dst = static_cast<const T*>(p);
-  return EG_OK;
+void put(std::vector<uint8_t>& blob, size_t off, const std::vector<T>& v, size_t max_count) {
+  const size_t n = v.size() < max_count ? v.size() : max_count;
+  if (n) std::memcpy(blob.data() + off, v.data(), sizeof(T) * n);
 }
 
 void free_outputs(eg_ctx* c) {
@@ -186,10 +164,17 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   const HostTables& H = c->tables.H;
   DevTables& D = c->dev;
   int rc = EG_OK;
-  auto up = [&](auto& vec, auto** dst) { if (rc == EG_OK) rc = upload_vec(c, vec, dst); };
-  up(H.usage, &D.usage); up(H.population, &D.population);
-  up(H.pre_co2, &D.pre_co2); up(H.pre_tg, &D.pre_tg); up(H.pre_ig, &D.pre_ig); up(H.pre_sg, &D.pre_sg);
-  up(H.pre_optot, &D.pre_optot); up(H.pre_opcnt, &D.pre_opcnt);
+  std::vector<uint8_t> blob(tab::total, 0);
+  put(blob, tab::usage, H.usage, kYears); put(blob, tab::population, H.population, kYears);
+  put(blob, tab::pre_co2, H.pre_co2, kYears); put(blob, tab::pre_tg, H.pre_tg, kYears); put(blob, tab::pre_ig, H.pre_ig, kYears);
+  put(blob, tab::pre_sg, H.pre_sg, kYears); put(blob, tab::pre_optot, H.pre_optot, kYears); put(blob, tab::pre_opcnt, H.pre_opcnt, kYears);
+  put(blob, tab::inflation, H.inflation, kYears); put(blob, tab::carbon_price, H.carbon_price, kYears);
+  put(blob, tab::out_mw, H.out_mw, kTypes); put(blob, tab::co2_t, H.co2_t, kTypes);
+  put(blob, tab::cls, H.cls, kTypes); put(blob, tab::rclass, H.rclass, kTypes); put(blob, tab::marine, H.marine, kTypes);
+  put(blob, tab::reach, H.reach, kRadiusClasses);
+  put(blob, tab::dr, H.dr, size_t(kRadiusClasses) * 169); put(blob, tab::m03, H.m03, kCells); put(blob, tab::t12, H.t12, size_t(kYears) * kTypes);
+  put(blob, tab::offv, H.offv, size_t(kYears) * kOffsetTypes * kYears); put(blob, tab::offc, H.offc, size_t(kYears) * kOffsetTypes * kMults);
+  put(blob, tab::cc, H.cc, size_t(kYears) * kTypes * kYears * kMults * 2);
   {  // Sorted candidate lists.  final(c) = ((te[c] * prod_g d/R) * cf[c]) * size <= base(c) = (te[c] * cf[c]) * size
      // because every factor is in [0, 1] and IEEE multiplication is monotone, so a scan in descending base order can
      // stop as soon as the next base is below the best final score found (k_rollout / place_search).
@@ -203,34 +188,37 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       variant_of[t] = int32_t(v);
     }
     const int NV = int(variants.size());
-    std::vector<uint16_t> ps_cell(size_t(kYears) * NV * kPsStride, 0);
-    std::vector<double> ps_te(size_t(kYears) * NV * kPsStride, 0.0), ps_cf(size_t(kYears) * NV * kPsStride, 1.0);
-    std::vector<double> ps_m03(size_t(kYears) * NV * kPsStride, 0.0);
+    if (NV > kMaxVariants) { set_error("eg_create: too many (radius class, marine) variants"); rc = EG_ERR_BAD_ARG; }
+    put(blob, tab::variant, variant_of, kTypes);
+    PsRec* ps = reinterpret_cast<PsRec*>(blob.data() + tab::ps);   // entries beyond the 2601 candidates stay te = 0
     std::vector<double> base(kCells);
     std::vector<int> order(kCells);
-    for (int y = 0; y < kYears; ++y)
+    for (int y = 0; y < kYears && rc == EG_OK; ++y)
       for (int v = 0; v < NV; ++v) {
         const double* te = &H.te[(size_t(y) * kRadiusClasses + variants[v].first) * kCells];
         const bool marine = variants[v].second != 0;
-        for (int c = 0; c < kCells; ++c) { base[c] = (te[c] * (marine ? H.coastf[c] : 1.0)) * H.size_factor; order[c] = c; }
+        for (int c2 = 0; c2 < kCells; ++c2) { base[c2] = (te[c2] * (marine ? H.coastf[c2] : 1.0)) * H.size_factor; order[c2] = c2; }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return base[a] > base[b]; });
-        const size_t o = (size_t(y) * NV + v) * kPsStride;
+        PsRec* list = ps + (size_t(y) * kMaxVariants + v) * kPsStride;
+        for (int r = 0; r < kPsStride; ++r) { list[r].te = 0.0; list[r].cf = 1.0; list[r].m03 = 0.0; list[r].cell = 0; list[r].pad = 0; }
         for (int r = 0; r < kCells; ++r) {
-          ps_cell[o + r] = uint16_t(order[r]); ps_te[o + r] = te[order[r]]; ps_cf[o + r] = marine ? H.coastf[order[r]] : 1.0;
-          ps_m03[o + r] = H.m03[order[r]];
+          list[r].te = te[order[r]]; list[r].cf = marine ? H.coastf[order[r]] : 1.0; list[r].m03 = H.m03[order[r]]; list[r].cell = uint32_t(order[r]);
         }
       }
-    up(ps_cell, &D.ps_cell); up(ps_te, &D.ps_te); up(ps_cf, &D.ps_cf); up(ps_m03, &D.ps_m03); up(variant_of, &D.variant);
-    D.n_variants = NV;
   }
-  up(H.dr, &D.dr);
-  up(H.m03, &D.m03); up(H.t12, &D.t12); up(H.cc, &D.cc); up(H.out_mw, &D.out_mw); up(H.co2_t, &D.co2_t);
-  up(H.cls, &D.cls); up(H.rclass, &D.rclass); up(H.marine, &D.marine); up(H.reach, &D.reach);
-  up(H.offv, &D.offv); up(H.offc, &D.offc); up(H.inflation, &D.inflation); up(H.carbon_price, &D.carbon_price);
+  if (rc == EG_OK) {
+    void* p = nullptr;
+    if (hipMalloc(&p, tab::total) != hipSuccess) { set_error("hipMalloc(tables) failed"); rc = EG_ERR_HIP; }
+    else {
+      c->allocs.push_back(p);
+      if (hipMemcpy(p, blob.data(), tab::total, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy(tables) failed"); rc = EG_ERR_HIP; }
+      D.base = static_cast<const uint8_t*>(p);
+    }
+  }
   D.size_factor = H.size_factor; D.n_existing = world->n_existing;
   if (rc == EG_OK && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
   if (rc == EG_OK) {
-    if (hipMalloc((void**)&c->d_snap, kSnapBytes) != hipSuccess || hipHostMalloc((void**)&c->h_snap, kSnapBytes) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_snap, snap::total) != hipSuccess || hipHostMalloc((void**)&c->h_snap, snap::total) != hipSuccess) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
     }
   }
@@ -285,12 +273,12 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   const bool have_lists = s->has_best && s->best_count && s->best_actions && s->best_deficit_count && s->best_deficit_actions;
   int32_t off[28] = {0}, offd[28] = {0};
   if (have_lists) for (int y = 0; y < EG_YEARS; ++y) { off[y + 1] = off[y] + s->best_count[y]; offd[y + 1] = offd[y] + s->best_deficit_count[y]; }
-  if (size_t(off[26]) > kSnapBestCap || size_t(offd[26]) > kSnapBestCap) { set_error("eg_upload_snapshot: best action lists too long"); return EG_ERR_BAD_ARG; }
+  if (size_t(off[26]) > snap::kBestCap || size_t(offd[26]) > snap::kBestCap) { set_error("eg_upload_snapshot: best action lists too long"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipStreamSynchronize(nullptr));   // the pinned staging buffer may still feed the previous copy
   uint8_t* h = c->h_snap;
-  std::memcpy(h + kSnapW, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
-  std::memcpy(h + kSnapDw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT);
-  if (s->count_weights) std::memcpy(h + kSnapCw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS);
+  std::memcpy(h + snap::w, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
+  std::memcpy(h + snap::dw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT);
+  if (s->count_weights) std::memcpy(h + snap::cw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS);
   {  // sampling.rs:182, :352-355, :406: the sums the samplers start from, folded in table order like the device does
     double tot[EG_YEARS * 3];
     for (int y = 0; y < EG_YEARS; ++y) {
@@ -300,14 +288,14 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
       if (s->count_weights) for (int i = 0; i < EG_N_COUNTS; ++i) c2 += s->count_weights[y * EG_N_COUNTS + i];
       tot[3 * y] = a; tot[3 * y + 1] = b; tot[3 * y + 2] = c2;
     }
-    std::memcpy(h + kSnapTotals, tot, sizeof(tot));
+    std::memcpy(h + snap::row_totals, tot, sizeof(tot));
   }
   if (s->iterations_without_improvement > 500u) {   // sampling.rs:190-220 on the un-nudged rows
     const double stagnation = std::fmin(double(s->iterations_without_improvement) / 1000.0, 3.0);
     const double power = 1.0 + (2.0 * stagnation);
-    double* scaled = reinterpret_cast<double*>(h + kSnapScaled);
-    double* totals = reinterpret_cast<double*>(h + kSnapScaledTotal);
-    uint8_t* perm = h + kSnapPerm;
+    double* scaled = reinterpret_cast<double*>(h + snap::scaled);
+    double* totals = reinterpret_cast<double*>(h + snap::scaled_total);
+    uint8_t* perm = h + snap::scaled_perm;
     for (int y = 0; y < EG_YEARS; ++y) {
       const double* w = s->weights + y * EG_N_ACTIONS;
       int order[EG_N_ACTIONS];
@@ -324,18 +312,13 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
       for (int i = off[y]; i < off[y + 1]; ++i) if (s->best_actions[i] < 64) mask[y] |= 1ull << s->best_actions[i];
       for (int i = offd[y]; i < offd[y + 1]; ++i) if (s->best_deficit_actions[i] < 64) { mask[y] |= 1ull << s->best_deficit_actions[i]; dmask[y] |= 1ull << s->best_deficit_actions[i]; }
     }
-  std::memcpy(h + kSnapMask, mask, sizeof(mask)); std::memcpy(h + kSnapDmask, dmask, sizeof(dmask));
-  std::memcpy(h + kSnapOff, off, sizeof(off)); std::memcpy(h + kSnapOffd, offd, sizeof(offd));
-  if (have_lists) { std::memcpy(h + kSnapBest, s->best_actions, size_t(off[26])); std::memcpy(h + kSnapBestd, s->best_deficit_actions, size_t(offd[26])); }
-  EG_HIP(hipMemcpyAsync(c->d_snap, h, kSnapBytes, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
+  std::memcpy(h + snap::best_mask, mask, sizeof(mask)); std::memcpy(h + snap::bestd_mask, dmask, sizeof(dmask));
+  std::memcpy(h + snap::best_off, off, sizeof(off)); std::memcpy(h + snap::bestd_off, offd, sizeof(offd));
+  if (have_lists) { std::memcpy(h + snap::best_actions, s->best_actions, size_t(off[26])); std::memcpy(h + snap::bestd_actions, s->best_deficit_actions, size_t(offd[26])); }
+  EG_HIP(hipMemcpyAsync(c->d_snap, h, snap::total, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
   DevSnapshot& S = c->snap;
   S = DevSnapshot{};
-  S.w = reinterpret_cast<const double*>(c->d_snap + kSnapW); S.dw = reinterpret_cast<const double*>(c->d_snap + kSnapDw);
-  S.cw = s->count_weights ? reinterpret_cast<const double*>(c->d_snap + kSnapCw) : nullptr;
-  S.row_totals = reinterpret_cast<const double*>(c->d_snap + kSnapTotals);
-  S.scaled = reinterpret_cast<const double*>(c->d_snap + kSnapScaled);
-  S.scaled_total = reinterpret_cast<const double*>(c->d_snap + kSnapScaledTotal);
-  S.scaled_perm = c->d_snap + kSnapPerm;
+  S.base = c->d_snap; S.has_cw = s->count_weights ? 1 : 0;
   S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
   S.has_best = s->has_best ? 1 : 0;
   // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)
@@ -347,10 +330,6 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   const double scaled = std::pow(s->exploration_rate, 0.5);   // sampling.rs:425-427
   S.heur_min = uint32_t(std::round(2.0 / scaled)); S.heur_max = uint32_t(std::round(12.0 / scaled));
   S.has_best_actions = have_lists ? 1 : 0; S.has_best_deficit = have_lists ? 1 : 0;
-  S.best_off = reinterpret_cast<const int32_t*>(c->d_snap + kSnapOff); S.bestd_off = reinterpret_cast<const int32_t*>(c->d_snap + kSnapOffd);
-  S.best_actions = c->d_snap + kSnapBest; S.bestd_actions = c->d_snap + kSnapBestd;
-  S.best_mask = reinterpret_cast<const unsigned long long*>(c->d_snap + kSnapMask);
-  S.bestd_mask = reinterpret_cast<const unsigned long long*>(c->d_snap + kSnapDmask);
   {  // learning.rs:134-180: everything of the contrast step that depends only on the snapshot
     StatsParams& P = c->stats_params;
     const double k = double(s->iterations_without_improvement);

@@ -1,5 +1,6 @@
 // eg_internal.h — layouts shared by the host table builder, the C ABI glue and the HIP kernels.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -55,51 +56,103 @@ struct HostTables {
 
 void build_tables(const eg_world& w, HostTables& t);
 
-// Device view (raw pointers into HBM), passed to kernels by value.
+#ifdef __HIPCC__
+#define EG_HD __host__ __device__
+#else
+#define EG_HD
+#endif
+
+// One entry of a sorted candidate list: everything the placement search reads about a candidate, 32 bytes.
+struct PsRec { double te, cf, m03; uint32_t cell, pad; };
+static_assert(sizeof(PsRec) == 32, "candidate record");
+
+// Device tables: ONE allocation, fixed layout.  A kernel receives a single base pointer and addresses every table at a
+// compile-time offset, so a table access costs no kernel-argument load and no pointer registers.
+namespace tab {
+constexpr size_t a16(size_t x) { return (x + 15) & ~size_t(15); }
+constexpr size_t usage = 0;
+constexpr size_t population = usage + 8 * kYears;
+constexpr size_t pre_co2 = population + 8 * kYears;
+constexpr size_t pre_tg = pre_co2 + 8 * kYears;
+constexpr size_t pre_ig = pre_tg + 8 * kYears;
+constexpr size_t pre_sg = pre_ig + 8 * kYears;
+constexpr size_t pre_optot = pre_sg + 8 * kYears;
+constexpr size_t inflation = pre_optot + 8 * kYears;
+constexpr size_t carbon_price = inflation + 8 * kYears;
+constexpr size_t out_mw = carbon_price + 8 * kYears;
+constexpr size_t co2_t = out_mw + 8 * 16;
+constexpr size_t pre_opcnt = co2_t + 8 * 16;
+constexpr size_t variant = a16(pre_opcnt + 4 * kYears);
+constexpr size_t cls = variant + 4 * 16;
+constexpr size_t rclass = cls + 4 * 16;
+constexpr size_t marine = rclass + 4 * 16;
+constexpr size_t reach = marine + 4 * 16;
+constexpr size_t dr = a16(reach + 4 * 8);                                   // [6][13][13]
+constexpr size_t m03 = a16(dr + 8 * kRadiusClasses * 169);                  // [2601]
+constexpr size_t t12 = a16(m03 + 8 * kCells);                               // [26][15]
+constexpr size_t offv = a16(t12 + 8 * kYears * kTypes);                     // [26][4][26]
+constexpr size_t offc = a16(offv + 8 * kYears * kOffsetTypes * kYears);     // [26][4][3]
+constexpr size_t cc = a16(offc + 8 * kYears * kOffsetTypes * kMults);       // [26][15][26][3][2]
+constexpr size_t ps = a16(cc + 8 * size_t(kYears) * kTypes * kYears * kMults * 2);   // PsRec [26][kMaxVariants][kPsStride]
+constexpr size_t total = ps + sizeof(PsRec) * size_t(kYears) * kMaxVariants * kPsStride;
+}  // namespace tab
+
 struct DevTables {
-  const double* usage; const double* population;
-  const double* pre_co2; const double* pre_tg; const double* pre_ig; const double* pre_sg; const double* pre_optot;
-  const int32_t* pre_opcnt;
-  // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  const uint16_t* ps_cell; const double* ps_te; const double* ps_cf; const double* ps_m03;   // [26][n_variants][kPsStride]
-  const int32_t* variant;   // [15] type -> variant
-  int32_t n_variants;
-  const double* dr; double size_factor;
-  const double* m03; const double* t12; const double* cc;
-  const double* out_mw; const double* co2_t;
-  const int32_t* cls; const int32_t* rclass; const int32_t* marine; const int32_t* reach;
-  const double* offv; const double* offc;
-  const double* inflation; const double* carbon_price;
+  const uint8_t* base;
+  double size_factor;
   int32_t n_existing;
+#define EG_TAB(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + tab::name); }
+  EG_TAB(usage, double) EG_TAB(population, double)
+  EG_TAB(pre_co2, double) EG_TAB(pre_tg, double) EG_TAB(pre_ig, double) EG_TAB(pre_sg, double) EG_TAB(pre_optot, double)
+  EG_TAB(inflation, double) EG_TAB(carbon_price, double) EG_TAB(out_mw, double) EG_TAB(co2_t, double)
+  EG_TAB(pre_opcnt, int32_t) EG_TAB(variant, int32_t) EG_TAB(cls, int32_t) EG_TAB(rclass, int32_t) EG_TAB(marine, int32_t)
+  EG_TAB(reach, int32_t)
+  EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
+  // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
+  EG_TAB(ps, PsRec)
+#undef EG_TAB
 };
 
-// Policy snapshot in HBM
+// Policy snapshot in HBM: one packed buffer (filled by one copy from pinned memory), fixed layout.
+namespace snap {
+constexpr size_t kBestCap = 4096;     // best_actions can hold every replay-doubled year list
+constexpr size_t w = 0;                                                     // [26][61]
+constexpr size_t dw = w + 8 * EG_YEARS * EG_N_ACTIONS;                      // [26][15]
+constexpr size_t cw = dw + 8 * EG_YEARS * EG_N_DEFICIT;                     // [26][21] (has_cw)
+constexpr size_t row_totals = cw + 8 * EG_YEARS * EG_N_COUNTS;              // [26][3] sums of the w / dw (first 14) / cw rows
+// stalled sampler (sampling.rs:190-220, stall > 500): per year the weights raised to the power in stable descending
+// order, the permutation and the sum, evaluated on the host with the shared eg_detpow; valid until the first nudge
+constexpr size_t scaled = row_totals + 8 * EG_YEARS * 3;                    // [26][64]
+constexpr size_t scaled_total = scaled + 8 * EG_YEARS * 64;                 // [26]
+constexpr size_t scaled_perm = scaled_total + 8 * EG_YEARS;                 // u8 [26][64]
+constexpr size_t best_mask = scaled_perm + 64 * EG_YEARS;                   // u64 [26] bit a: a occurs in best(y) or best_deficit(y)
+constexpr size_t bestd_mask = best_mask + 8 * EG_YEARS;                     // u64 [26] bit a: a occurs in best_deficit(y)
+constexpr size_t best_off = bestd_mask + 8 * EG_YEARS;                      // i32 [27(+1)] prefix offsets into best_actions
+constexpr size_t bestd_off = best_off + 4 * 28;
+constexpr size_t best_actions = bestd_off + 4 * 28;                         // u8 [kBestCap]
+constexpr size_t bestd_actions = best_actions + kBestCap;
+constexpr size_t total = bestd_actions + kBestCap;
+}  // namespace snap
+
 struct DevSnapshot {
-  const double* w;    // [26][61]
-  const double* dw;   // [26][15]
-  const double* cw;   // [26][21] or nullptr
-  const double* row_totals;   // [26][3] table-order sums of the w / dw (first 14) / cw rows of each year (host-evaluated)
-  // stalled sampler (sampling.rs:190-220, stall > 500): per year the weights raised to the power in stable descending
-  // order, the permutation and the sum, evaluated on the host with the shared eg_detpow; valid until the first nudge
-  const double* scaled;       // [26][64]
-  const uint8_t* scaled_perm; // [26][64]
-  const double* scaled_total; // [26]
+  const uint8_t* base;
   double learning_rate, exploration_rate;
   uint32_t stall;
   int32_t has_best;
+  int32_t has_cw;              // the count table is present (else: heuristic count, sampling.rs:425-427)
   int32_t noop_boost;          // best is net-zero but above 8x the acceptable cost (learning.rs:82)
   double rel_improvement;      // learning.rs:37-49 evaluated on the host
   double immediate_weight;     // learning.rs:54
   int32_t has_best_actions, has_best_deficit;
   uint32_t heur_min, heur_max;   // sampling.rs:425-427 evaluated on the host (count table absent)
-  const int32_t* best_off;     // [27] prefix offsets into best_actions
-  const uint8_t* best_actions;
-  const int32_t* bestd_off;    // [27]
-  const uint8_t* bestd_actions;
-  const unsigned long long* best_mask;   // [26] bit a set: action a occurs in best_actions[y] or best_deficit_actions[y]
-  const unsigned long long* bestd_mask;  // [26] bit a set: action a occurs in best_deficit_actions[y]
   int32_t enable_energy_sales;
   int32_t write_yearly;
+#define EG_SNAP(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + snap::name); }
+  EG_SNAP(w, double) EG_SNAP(dw, double) EG_SNAP(cw, double) EG_SNAP(row_totals, double)
+  EG_SNAP(scaled, double) EG_SNAP(scaled_total, double) EG_SNAP(scaled_perm, uint8_t)
+  EG_SNAP(best_mask, unsigned long long) EG_SNAP(bestd_mask, unsigned long long)
+  EG_SNAP(best_off, int32_t) EG_SNAP(bestd_off, int32_t) EG_SNAP(best_actions, uint8_t) EG_SNAP(bestd_actions, uint8_t)
+#undef EG_SNAP
 };
 
 // Per-batch output buffers in HBM (episode-major)

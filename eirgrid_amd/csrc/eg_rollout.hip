@@ -205,17 +205,17 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 
 // small per-type / per-class tables -> LDS (one dependent LDS read instead of chains of L2 round trips)
 __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane) {
-  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr[i];
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr()[i];
   if (lane < kTypes) {
-    const int rc = T.rclass[lane];
-    sm.type_info[lane] = T.variant[lane] | (rc << 4) | (T.reach[rc] << 8) | (T.cls[lane] << 12);
-    sm.type_out[lane] = T.out_mw[lane];
-    sm.type_co2[lane] = T.co2_t[lane];
+    const int rc = T.rclass()[lane];
+    sm.type_info[lane] = T.variant()[lane] | (rc << 4) | (T.reach()[rc] << 8) | (T.cls()[lane] << 12);
+    sm.type_out[lane] = T.out_mw()[lane];
+    sm.type_co2[lane] = T.co2_t()[lane];
   }
   if (lane < EG_YEARS) {
-    sm.yr[0][lane] = T.pre_co2[lane]; sm.yr[1][lane] = T.pre_tg[lane]; sm.yr[2][lane] = T.pre_ig[lane]; sm.yr[3][lane] = T.pre_sg[lane];
-    sm.yr[4][lane] = T.pre_optot[lane]; sm.yr[5][lane] = T.usage[lane]; sm.yr[6][lane] = T.population[lane];
-    sm.yr[7][lane] = T.inflation[lane]; sm.yr[8][lane] = T.carbon_price[lane]; sm.yr_opcnt[lane] = T.pre_opcnt[lane];
+    sm.yr[0][lane] = T.pre_co2()[lane]; sm.yr[1][lane] = T.pre_tg()[lane]; sm.yr[2][lane] = T.pre_ig()[lane]; sm.yr[3][lane] = T.pre_sg()[lane];
+    sm.yr[4][lane] = T.pre_optot()[lane]; sm.yr[5][lane] = T.usage()[lane]; sm.yr[6][lane] = T.population()[lane];
+    sm.yr[7][lane] = T.inflation()[lane]; sm.yr[8][lane] = T.carbon_price()[lane]; sm.yr_opcnt[lane] = T.pre_opcnt()[lane];
   }
 }
 
@@ -340,11 +340,10 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     const int ngen_s = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][1]);
     if (c0 < 0) return;
     const int yi = c0 & 31, v = (c0 >> 8) & 15, rc = (c0 >> 12) & 15;
-    const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
     const int r = h * kWave + lane;
-    const double te = T.ps_te[o + r], cf = T.ps_cf[o + r], m03 = T.ps_m03[o + r]; const int cell = T.ps_cell[o + r];
-    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, te, cf, cell);
-    const ChunkBest b = chunk_reduce(s, cell, m03);
+    const PsRec c = T.ps()[(size_t)(yi * kMaxVariants + v) * kPsStride + r];
+    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell);
+    const ChunkBest b = chunk_reduce(s, (int)c.cell, c.m03);
     if (lane == 0) { sm.hres[h - 1].score = b.score; sm.hres[h - 1].m03 = b.m03; sm.hres[h - 1].cell = b.cell; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *(volatile uint32_t*)&sm.hflag[h - 1] = sq;
@@ -356,11 +355,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
                                             double* best_m03, uint32_t* seq = nullptr, unsigned long long* stamps = nullptr) {
   const int info = sm.type_info[type];
   const int v = info & 15, rc = (info >> 4) & 15;
-  const size_t o = ((size_t)yi * T.n_variants + v) * kPsStride;
-  const uint16_t* __restrict__ cells = T.ps_cell + o;
-  const double* __restrict__ tes = T.ps_te + o;
-  const double* __restrict__ cfs = T.ps_cf + o;
-  const double* __restrict__ m03s = T.ps_m03 + o;
+  const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
   const double* dr = sm.dr + rc * 169;
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
@@ -369,11 +364,12 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   int first = 0;
   bool more = true;
   // chunk 0 is loaded here, chunk k+1 while chunk k is being evaluated
-  double te = tes[lane], cf = cfs[lane], m03 = m03s[lane]; int cell = cells[lane];
+  PsRec c = list[lane];
   if constexpr (kHelpers > 0) {
     // lanes 0..kHelpers: unpenalised score of the first candidate of chunks 1..kHelpers+1 = the bound of that chunk
     const int bl = (lane <= kHelpers ? lane + 1 : 1) * kWave;
-    const double bound = (tes[bl] * cfs[bl]) * size_factor;
+    const PsRec cb = list[bl];
+    const double bound = (cb.te * cb.cf) * size_factor;
     *seq += 1;
     const uint32_t sq = *seq;
     if (lane == 0) { sm.cmd[sq & 1][0] = yi | (v << 8) | (rc << 12); sm.cmd[sq & 1][1] = ngen_s; }
@@ -382,12 +378,12 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, te, cf, cell);
+    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
 #endif
-    const ChunkBest b0 = chunk_reduce(s0, cell, m03);
+    const ChunkBest b0 = chunk_reduce(s0, (int)c.cell, c.m03);
     if (b0.score > 0.0) { best = b0.score; best_c = b0.cell; m03w = b0.m03; }
     for (int h = 1; h <= kHelpers && more; ++h) {
       if (!(readlane_f64(bound, h - 1) >= best)) { more = false; break; }
@@ -401,17 +397,17 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     }
     if (more && !(readlane_f64(bound, kHelpers) >= best)) more = false;
     first = kHelpers + 1;
-    if (more) { const int r = first * kWave + lane; te = tes[r]; cf = cfs[r]; m03 = m03s[r]; cell = cells[r]; }
+    if (more) c = list[first * kWave + lane];
 #ifdef EG_STAMPS
     if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
 #endif
   }
   for (int chunk = first; more && chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
-    const double base = (te * cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
+    const double base = (c.te * c.cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
     if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
-    const double te_cur = te, cf_cur = cf, m03_cur = m03; const int cell_cur = cell;
-    if (chunk + 1 < kChunks) { te = tes[r + kWave]; cf = cfs[r + kWave]; m03 = m03s[r + kWave]; cell = cells[r + kWave]; }
+    const double te_cur = c.te, cf_cur = c.cf, m03_cur = c.m03; const int cell_cur = (int)c.cell;
+    if (chunk + 1 < kChunks) c = list[r + kWave];
 #ifdef EG_STAMPS
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
@@ -620,14 +616,14 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
   int rp = 0, dp = 0;
   for (int y = 0; y < EG_YEARS; ++y) {
     const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
-    const unsigned long long mask = S.best_mask[y], dmask = S.bestd_mask[y];
-    const int b0 = S.best_off[y], nb = S.best_off[y + 1] - b0, d0 = S.bestd_off[y], nbd = S.bestd_off[y + 1] - d0;
+    const unsigned long long mask = S.best_mask()[y], dmask = S.bestd_mask()[y];
+    const int b0 = S.best_off()[y], nb = S.best_off()[y + 1] - b0, d0 = S.bestd_off()[y], nbd = S.bestd_off()[y + 1] - d0;
     for (int j = lane; j < nr + nd; j += kWave) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
       const int a = j < nr ? run[rp + j] : def[dp + (j - nr)];
       if (qualifies) {
         if (!((mask >> a) & 1ull)) atomicAdd(&st[8 + y * EG_N_ACTIONS + a], q_pen);
         else if (j < nb + nbd) {
-          const int b = j < nb ? S.best_actions[b0 + j] : S.bestd_actions[d0 + (j - nb)];
+          const int b = j < nb ? S.best_actions()[b0 + j] : S.bestd_actions()[d0 + (j - nb)];
           if (a != b) atomicAdd(&st[8 + kStatsMain + y * EG_N_ACTIONS + a], q_mild);
         }
       }
@@ -694,8 +690,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
   if (lane < 8) sm.acc[lane] = 0.0;   // [0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row
 
-  double nw = lane < EG_N_ACTIONS ? S.w[lane] : 0.0, ndw = lane < EG_N_DEFICIT ? S.dw[lane] : 0.0;
-  double ncw = (S.cw != nullptr && lane < EG_N_COUNTS) ? S.cw[lane] : 0.0;
+  double nw = lane < EG_N_ACTIONS ? S.w()[lane] : 0.0, ndw = lane < EG_N_DEFICIT ? S.dw()[lane] : 0.0;
+  double ncw = (S.has_cw && lane < EG_N_COUNTS) ? S.cw()[lane] : 0.0;
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
     {  // this year's policy rows -> LDS (they were requested a year ahead: nw / ndw / ncw), then request next year's
@@ -704,20 +700,20 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
     if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
     if (lane < EG_N_COUNTS) sm.cw[lane] = ncw;
-    if (S.stall > 500u) { sm.scaled[lane] = S.scaled[yi * 64 + lane]; sm.ydef[128 + lane] = S.scaled_perm[yi * 64 + lane]; }
+    if (S.stall > 500u) { sm.scaled[lane] = S.scaled()[yi * 64 + lane]; sm.ydef[128 + lane] = S.scaled_perm()[yi * 64 + lane]; }
     if (yi + 1 < kYears) {
-      if (lane < EG_N_ACTIONS) nw = S.w[(yi + 1) * EG_N_ACTIONS + lane];
-      if (lane < EG_N_DEFICIT) ndw = S.dw[(yi + 1) * EG_N_DEFICIT + lane];
-      if (S.cw != nullptr && lane < EG_N_COUNTS) ncw = S.cw[(yi + 1) * EG_N_COUNTS + lane];
+      if (lane < EG_N_ACTIONS) nw = S.w()[(yi + 1) * EG_N_ACTIONS + lane];
+      if (lane < EG_N_DEFICIT) ndw = S.dw()[(yi + 1) * EG_N_DEFICIT + lane];
+      if (S.has_cw && lane < EG_N_COUNTS) ncw = S.cw()[(yi + 1) * EG_N_COUNTS + lane];
     }
     wave_sync();
     EG_T1(5);
     }
     EG_MARKG(18);
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
-    Totals tot; tot.main = S.row_totals[3 * yi]; tot.deficit = S.row_totals[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
-    tot.scaled = S.stall > 500u ? S.scaled_total[yi] : 0.0; tot.scaled_valid = true;
-    const double cw_total = S.row_totals[3 * yi + 2];
+    Totals tot; tot.main = S.row_totals()[3 * yi]; tot.deficit = S.row_totals()[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
+    tot.scaled = S.stall > 500u ? S.scaled_total()[yi] : 0.0; tot.scaled_valid = true;
+    const double cw_total = S.row_totals()[3 * yi + 2];
     EG_TE(14);
 
     // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
@@ -735,8 +731,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       const bool carry = yi > 0 && pco2 == sm.yr[0][yi - 1] && ptg == sm.yr[1][yi - 1] && pig == sm.yr[2][yi - 1] && psg == sm.yr[3][yi - 1];
       if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
       else { a.co2 = pco2; a.tg = ptg; a.ig = pig; a.sg = psg; }
-      const double* ccy = T.cc + (size_t)yi * kTypes * kYears * kMults * 2;
-      const double* t12y = T.t12 + (size_t)yi * kTypes;
+      const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
+      const double* t12y = T.t12() + (size_t)yi * kTypes;
       const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
       for (int base = 0; base < ngen_s; base += kWave) {
         const int g = base + lane;
@@ -744,7 +740,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
         const int cell = gc & 0xFFF, t = gc >> 12, b = bm & 31, m = bm >> 5;
         const double2 cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t * kYears + b) * kMults + m) * 2);
-        const double op = (T.m03[cell] + t12y[t]) + cc.y;
+        const double op = (T.m03()[cell] + t12y[t]) + cc.y;
         double out = 0.0, co2 = 0.0; int cls = 0;
         if (!carry) { out = sm.type_out[t]; co2 = sm.type_co2[t]; cls = (sm.type_info[t] >> 12) & 3; }
         const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
@@ -768,8 +764,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         }
         a.opcnt += cnt;
       }
-      const double* offvy = T.offv + (size_t)yi * kOffsetTypes * kYears;
-      const double* offcy = T.offc + (size_t)yi * kOffsetTypes * kMults;
+      const double* offvy = T.offv() + (size_t)yi * kOffsetTypes * kYears;
+      const double* offcy = T.offc() + (size_t)yi * kOffsetTypes * kMults;
       const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
       for (int base = 0; base < noff_s; base += kWave) {
         const int k = base + lane;
@@ -815,8 +811,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         EG_MARKG(19);
         if (attempts < 5u) {
           if (replay) {   // sampling.rs:242-313
-            const int lo = S.bestd_off[yi], n = S.bestd_off[yi + 1] - lo;
-            if (S.has_best_deficit && replay_def_idx < n) { action = S.bestd_actions[lo + replay_def_idx]; replay_def_idx += 1; }
+            const int lo = S.bestd_off()[yi], n = S.bestd_off()[yi + 1] - lo;
+            if (S.has_best_deficit && replay_def_idx < n) { action = S.bestd_actions()[lo + replay_def_idx]; replay_def_idx += 1; }
             else action = smart_deficit_fallback(rng, lane);
             if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; break; }
             if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
@@ -831,13 +827,13 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
           n_add_known = true;
           EG_MARKG(24);
           if (replay) {
-            n_add = S.has_best_actions ? (uint32_t)(S.best_off[yi + 1] - S.best_off[yi]) : 0u;
+            n_add = S.has_best_actions ? (uint32_t)(S.best_off()[yi + 1] - S.best_off()[yi]) : 0u;
           } else {   // sampling.rs:380-443
             const uint32_t dcount = (uint32_t)ep.n_def_y;
             const uint32_t cap = dcount >= 20u ? 0u : 20u - dcount;
             if (cap > 0u) {
               const double u = rng_f64(rng, lane);
-              if (S.cw != nullptr) {
+              if (S.has_cw) {
                 const double* cw = sm.cw;
                 const double total = cw_total;   // the count table is never nudged (Q3): its sum is a snapshot constant
                 if (total > 0.0) {
@@ -859,8 +855,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         k_add += 1;
         EG_MARKG(19);
         if (replay) {   // sampling.rs:78-145
-          const int lo = S.best_off[yi], n = S.best_off[yi + 1] - lo;
-          if (S.has_best_actions && replay_idx < n) { action = S.best_actions[lo + replay_idx]; replay_idx += 1; }
+          const int lo = S.best_off()[yi], n = S.best_off()[yi + 1] - lo;
+          if (S.has_best_actions && replay_idx < n) { action = S.best_actions()[lo + replay_idx]; replay_idx += 1; }
           else action = smart_fallback(rng, lane, year);
           if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
           if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
@@ -874,9 +870,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         const int t = action / 3, m = action - 3 * t;
         ep.bytes += (double)kCells * 8.0 + (double)(n_existing + ep.ngen) * 16.0;
         // terms that depend only on (year, type, multiplier) are requested before the search and land while it runs
-        const double2 ccv = *reinterpret_cast<const double2*>(T.cc + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
-        const double cc_prev = yi > 0 ? T.cc[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
-        const double t12v = T.t12[(size_t)yi * kTypes + t];
+        const double2 ccv = *reinterpret_cast<const double2*>(T.cc() + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
+        const double cc_prev = yi > 0 ? T.cc()[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
+        const double t12v = T.t12()[(size_t)yi * kTypes + t];
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
@@ -915,9 +911,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
         wave_sync();
         ep.noff += 1;
-        a.offs += T.offv[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
-        a.ocost += T.offc[((size_t)yi * kOffsetTypes + ot) * kMults + m];
-        if (yi > 0) a.ocost_prev += T.offc[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
+        a.offs += T.offv()[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
+        a.ocost += T.offc()[((size_t)yi * kOffsetTypes + ot) * kMults + m];
+        if (yi > 0) a.ocost_prev += T.offc()[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
         EG_TE(13);
       }
       // 57..59 carry an empty generator id (core.rs:117-119): the lookup fails, nothing changes.  60: DoNothing.
