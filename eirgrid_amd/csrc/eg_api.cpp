@@ -82,39 +82,16 @@ void put(std::vector<uint8_t>& blob, size_t off, const std::vector<T>& v, size_t
 }
 
 void free_outputs(eg_ctx* c) {
-  void* ptrs[] = {c->out.metrics, c->out.yearly, c->out.status, c->out.n_run, c->out.n_def, c->out.n_act, c->out.run_log,
-                  c->out.def_log, c->out.act_log, c->out.n_gens, c->out.gen_cell, c->out.gen_pack, c->out.n_offsets,
-                  c->out.off_pack, c->out.n_draws, c->out.bytes_moved, c->out.score};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->out.base) (void)hipFree(c->out.base);
   c->out = DevOut{}; c->out_cap = 0;
 }
 
 int ensure_outputs(eg_ctx* c, uint32_t n) {
   if (n <= c->out_cap) return EG_OK;
   free_outputs(c);
-  const size_t N = n;
-  EG_HIP(hipMalloc((void**)&c->out.metrics, N * 4 * sizeof(double)));
-  EG_HIP(hipMalloc((void**)&c->out.yearly, N * EG_YEARS * EG_YEARLY_FIELDS * sizeof(double)));
-  EG_HIP(hipMalloc((void**)&c->out.status, N * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.n_run, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.n_def, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.n_act, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.run_log, N * EG_RUN_CAP));
-  EG_HIP(hipMalloc((void**)&c->out.def_log, N * EG_DEF_CAP));
-  EG_HIP(hipMalloc((void**)&c->out.act_log, N * EG_ACT_CAP));
-  EG_HIP(hipMalloc((void**)&c->out.n_gens, N * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.gen_cell, N * EG_MAX_GENS * sizeof(uint16_t)));
-  EG_HIP(hipMalloc((void**)&c->out.gen_pack, N * EG_MAX_GENS * sizeof(uint16_t)));
-  EG_HIP(hipMalloc((void**)&c->out.n_offsets, N * sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&c->out.off_pack, N * EG_MAX_OFFSETS * sizeof(uint16_t)));
-  EG_HIP(hipMalloc((void**)&c->out.n_draws, N * sizeof(unsigned long long)));
-  EG_HIP(hipMalloc((void**)&c->out.bytes_moved, N * sizeof(double)));
-  EG_HIP(hipMalloc((void**)&c->out.score, N * sizeof(double)));
-  // zero the year-count tables once so episodes that end early leave defined data behind
-  EG_HIP(hipMemset(c->out.n_run, 0, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMemset(c->out.n_def, 0, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMemset(c->out.n_act, 0, N * EG_YEARS * sizeof(int32_t)));
-  EG_HIP(hipMemset(c->out.yearly, 0, N * EG_YEARS * EG_YEARLY_FIELDS * sizeof(double)));
+  EG_HIP(hipMalloc((void**)&c->out.base, size_t(n) * rec::stride));
+  // zero once so episodes that end early leave defined year counts / rows behind
+  EG_HIP(hipMemset(c->out.base, 0, size_t(n) * rec::stride));
   c->out_cap = n;
   return EG_OK;
 }
@@ -407,16 +384,17 @@ int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
   if (rc != EG_OK) return rc;
   const size_t N = c->last_n;
   if (N == 0) return EG_OK;
+  // one strided copy per requested field: episode records are rec::stride bytes apart on the device
 #define EG_GET(field, count, type) \
-  if (o->field) EG_HIP(hipMemcpy(o->field, c->out.field, N * (count) * sizeof(type), hipMemcpyDeviceToHost))
+  if (o->field) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), c->out.base + rec::field, rec::stride, (count) * sizeof(type), N, hipMemcpyDeviceToHost))
   EG_GET(metrics, 4, double); EG_GET(yearly, EG_YEARS * EG_YEARLY_FIELDS, double); EG_GET(status, 1, int32_t);
   EG_GET(n_run, EG_YEARS, int32_t); EG_GET(n_def, EG_YEARS, int32_t); EG_GET(n_act, EG_YEARS, int32_t);
   EG_GET(run_log, EG_RUN_CAP, uint8_t); EG_GET(def_log, EG_DEF_CAP, uint8_t); EG_GET(act_log, EG_ACT_CAP, uint8_t);
   EG_GET(n_gens, 1, int32_t); EG_GET(gen_cell, EG_MAX_GENS, uint16_t); EG_GET(gen_pack, EG_MAX_GENS, uint16_t);
   EG_GET(n_offsets, 1, int32_t); EG_GET(off_pack, EG_MAX_OFFSETS, uint16_t);
   EG_GET(bytes_moved, 1, double);
+  EG_GET(n_draws, 1, uint64_t);
 #undef EG_GET
-  if (o->n_draws) EG_HIP(hipMemcpy(o->n_draws, c->out.n_draws, N * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return EG_OK;
 }
 
@@ -455,7 +433,7 @@ int32_t eg_update_stats(eg_ctx* c, int64_t* d_stats) {
 int32_t eg_fetch_scores(eg_ctx* c, double* scores) {
   if (!c || !scores) return EG_ERR_BAD_ARG;
   EG_HIP(hipSetDevice(c->device));
-  if (c->last_n) EG_HIP(hipMemcpy(scores, c->out.score, sizeof(double) * c->last_n, hipMemcpyDeviceToHost));
+  if (c->last_n) EG_HIP(hipMemcpy2D(scores, sizeof(double), c->out.base + rec::score, rec::stride, sizeof(double), c->last_n, hipMemcpyDeviceToHost));
   return EG_OK;
 }
 
@@ -463,11 +441,11 @@ int32_t eg_fetch_episode_lists(eg_ctx* c, uint32_t i, double metrics[4], int32_t
                                uint8_t* def_log) {
   if (!c || i >= c->last_n || !metrics || !n_run || !run_log || !n_def || !def_log) { set_error("eg_fetch_episode_lists: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  EG_HIP(hipMemcpy(metrics, c->out.metrics + size_t(i) * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
-  EG_HIP(hipMemcpy(n_run, c->out.n_run + size_t(i) * EG_YEARS, EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
-  EG_HIP(hipMemcpy(n_def, c->out.n_def + size_t(i) * EG_YEARS, EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
-  EG_HIP(hipMemcpy(run_log, c->out.run_log + size_t(i) * EG_RUN_CAP, EG_RUN_CAP, hipMemcpyDeviceToHost));
-  EG_HIP(hipMemcpy(def_log, c->out.def_log + size_t(i) * EG_DEF_CAP, EG_DEF_CAP, hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(metrics, c->out.metrics(i), 4 * sizeof(double), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(n_run, c->out.n_run(i), EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(n_def, c->out.n_def(i), EG_YEARS * sizeof(int32_t), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(run_log, c->out.run_log(i), EG_RUN_CAP, hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(def_log, c->out.def_log(i), EG_DEF_CAP, hipMemcpyDeviceToHost));
   return EG_OK;
 }
 

@@ -155,15 +155,38 @@ struct DevSnapshot {
 #undef EG_SNAP
 };
 
-// Per-batch output buffers in HBM (episode-major)
+// Per-batch outputs in HBM: one record per episode (everything an episode writes is contiguous), fixed layout.
+namespace rec {
+constexpr size_t metrics = 0;                         // f64 [4]
+constexpr size_t score = 32;                          // f64, written by the statistics pass
+constexpr size_t bytes_moved = 40;                    // f64
+constexpr size_t n_draws = 48;                        // u64
+constexpr size_t status = 56;                         // i32
+constexpr size_t n_gens = 60;                         // i32
+constexpr size_t n_offsets = 64;                      // i32 (+4 pad)
+constexpr size_t n_run = 72;                          // i32 [26]
+constexpr size_t n_def = n_run + 4 * EG_YEARS;
+constexpr size_t n_act = n_def + 4 * EG_YEARS;
+constexpr size_t yearly = n_act + 4 * EG_YEARS;       // f64 [26][21]
+constexpr size_t run_log = yearly + 8 * EG_YEARS * EG_YEARLY_FIELDS;
+constexpr size_t def_log = run_log + EG_RUN_CAP;
+constexpr size_t act_log = def_log + EG_DEF_CAP;
+constexpr size_t gen_cell = act_log + EG_ACT_CAP;     // u16 [512]
+constexpr size_t gen_pack = gen_cell + 2 * EG_MAX_GENS;
+constexpr size_t off_pack = gen_pack + 2 * EG_MAX_GENS;
+constexpr size_t stride = (off_pack + 2 * EG_MAX_OFFSETS + 63) & ~size_t(63);
+static_assert(yearly % 8 == 0 && gen_cell % 2 == 0, "record alignment");
+}  // namespace rec
+
 struct DevOut {
-  double* metrics; double* yearly; int32_t* status;
-  int32_t* n_run; int32_t* n_def; int32_t* n_act;
-  uint8_t* run_log; uint8_t* def_log; uint8_t* act_log;
-  int32_t* n_gens; uint16_t* gen_cell; uint16_t* gen_pack;
-  int32_t* n_offsets; uint16_t* off_pack;
-  unsigned long long* n_draws; double* bytes_moved;
-  double* score;   // written by k_update_stats
+  uint8_t* base;
+#define EG_REC(name, type) EG_HD type* name(uint32_t e) const { return reinterpret_cast<type*>(base + size_t(e) * rec::stride + rec::name); }
+  EG_REC(metrics, double) EG_REC(score, double) EG_REC(bytes_moved, double) EG_REC(n_draws, unsigned long long)
+  EG_REC(status, int32_t) EG_REC(n_gens, int32_t) EG_REC(n_offsets, int32_t)
+  EG_REC(n_run, int32_t) EG_REC(n_def, int32_t) EG_REC(n_act, int32_t) EG_REC(yearly, double)
+  EG_REC(run_log, uint8_t) EG_REC(def_log, uint8_t) EG_REC(act_log, uint8_t)
+  EG_REC(gen_cell, uint16_t) EG_REC(gen_pack, uint16_t) EG_REC(off_pack, uint16_t)
+#undef EG_REC
 };
 
 void set_error(const std::string& s);

@@ -595,12 +595,12 @@ __device__ double device_score(const double* m) {   // ai/metrics/scoring.rs:18-
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
 __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats) {
   unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
-  if (O.status[e] != EG_EP_OK) {
-    if (lane == 0) { atomicAdd(&st[1], 1ull); O.score[e] = -1.0; }
+  if (*O.status(e) != EG_EP_OK) {
+    if (lane == 0) { atomicAdd(&st[1], 1ull); *O.score(e) = -1.0; }
     return;
   }
-  const double score = device_score(O.metrics + (size_t)e * 4);
-  if (lane == 0) { atomicAdd(&st[0], 1ull); O.score[e] = score; }
+  const double score = device_score(O.metrics(e));
+  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
   const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
@@ -611,11 +611,11 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
     q_pen = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);    // learning.rs:177
     q_mild = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);   // learning.rs:247
   }
-  const uint8_t* run = O.run_log + (size_t)e * EG_RUN_CAP;
-  const uint8_t* def = O.def_log + (size_t)e * EG_DEF_CAP;
+  const uint8_t* run = O.run_log(e);
+  const uint8_t* def = O.def_log(e);
   int rp = 0, dp = 0;
   for (int y = 0; y < EG_YEARS; ++y) {
-    const int nr = O.n_run[(size_t)e * EG_YEARS + y], nd = O.n_def[(size_t)e * EG_YEARS + y];
+    const int nr = O.n_run(e)[y], nd = O.n_def(e)[y];
     const unsigned long long mask = S.best_mask()[y], dmask = S.bestd_mask()[y];
     const int b0 = S.best_off()[y], nb = S.best_off()[y + 1] - b0, d0 = S.bestd_off()[y], nbd = S.bestd_off()[y + 1] - d0;
     for (int j = lane; j < nr + nd; j += kWave) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
@@ -679,12 +679,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 
   Episode ep;
   ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32.0;
-  uint8_t* run_log = O.run_log + (size_t)e * EG_RUN_CAP;
-  uint8_t* def_log = O.def_log + (size_t)e * EG_DEF_CAP;
-  uint8_t* act_log = O.act_log + (size_t)e * EG_ACT_CAP;
-  uint16_t* gen_cell = O.gen_cell + (size_t)e * EG_MAX_GENS;
-  uint16_t* gen_pack = O.gen_pack + (size_t)e * EG_MAX_GENS;
-  uint16_t* off_pack = O.off_pack + (size_t)e * EG_MAX_OFFSETS;
+  uint8_t* run_log = O.run_log(e);
+  uint8_t* def_log = O.def_log(e);
+  uint8_t* act_log = O.act_log(e);
+  uint16_t* gen_cell = O.gen_cell(e);
+  uint16_t* gen_pack = O.gen_pack(e);
+  uint16_t* off_pack = O.off_pack(e);
 
   double gcost_end = 0.0, ocost_end = 0.0;                 // last year's end-of-year capital sums
   double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
@@ -964,8 +964,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       sm.acc[0] = total_cost; sm.acc[1] = total_credit; sm.acc[2] = total_sales;
       sm.acc[3] = s.net; sm.acc[4] = s.opinion; sm.acc[5] = total_capital; sm.acc[6] = s.balance;
     }
-    if (S.write_yearly && O.yearly != nullptr && lane == 0) {   // one lane: 21 adjacent 8-byte stores (merged pairwise)
-      double* row = O.yearly + ((size_t)e * kYears + yi) * EG_YEARLY_FIELDS;
+    if (S.write_yearly && lane == 0) {   // one lane: 21 adjacent 8-byte stores (merged pairwise)
+      double* row = O.yearly(e) + yi * EG_YEARLY_FIELDS;
       row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = sm.yr[6][yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
       row[EG_Y_BALANCE] = s.balance; row[EG_Y_OPINION] = s.opinion; row[EG_Y_YEARLY_CAPITAL] = yearly_capital;
       row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = sm.yr[7][yi]; row[EG_Y_CO2] = a.co2;
@@ -975,9 +975,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       row[EG_Y_YEARLY_TOTAL_COST] = yearly_total; row[EG_Y_TOTAL_COST] = total_cost;
     }
     if (lane == 0) {
-      O.n_run[(size_t)e * kYears + yi] = ep.n_run_y;
-      O.n_def[(size_t)e * kYears + yi] = ep.n_def_y;
-      O.n_act[(size_t)e * kYears + yi] = ep.n_act_y;
+      O.n_run(e)[yi] = ep.n_run_y;
+      O.n_def(e)[yi] = ep.n_def_y;
+      O.n_act(e)[yi] = ep.n_act_y;
     }
     gcost_end = a.gcost; ocost_end = a.ocost;
     co2_end = a.co2; tg_end = a.tg; ig_end = a.ig; sg_end = a.sg;
@@ -986,15 +986,15 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 
   wave_sync();
   if (lane == 0) {   // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
-    O.metrics[(size_t)e * 4 + 0] = sm.acc[3];
-    O.metrics[(size_t)e * 4 + 1] = sm.acc[4];
-    O.metrics[(size_t)e * 4 + 2] = sm.acc[5];
-    O.metrics[(size_t)e * 4 + 3] = sm.acc[6] >= 0.0 ? 1.0 : 0.0;
-    O.status[e] = ep.status;
-    O.n_gens[e] = ep.ngen;
-    O.n_offsets[e] = ep.noff;
-    O.n_draws[e] = (unsigned long long)rng.words;
-    O.bytes_moved[e] = ep.bytes;
+    O.metrics(e)[0] = sm.acc[3];
+    O.metrics(e)[1] = sm.acc[4];
+    O.metrics(e)[2] = sm.acc[5];
+    O.metrics(e)[3] = sm.acc[6] >= 0.0 ? 1.0 : 0.0;
+    *O.status(e) = ep.status;
+    *O.n_gens(e) = ep.ngen;
+    *O.n_offsets(e) = ep.noff;
+    *O.n_draws(e) = (unsigned long long)rng.words;
+    *O.bytes_moved(e) = ep.bytes;
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
   const int tid = threadIdx.x;
   double best = -1.0; int best_i = -1;
   for (uint32_t i = tid; i < n; i += 1024) {
-    const double sc = O.score[i];
+    const double sc = *O.score(i);
     if (sc > best) { best = sc; best_i = (int)i; }      // ascending i per thread: first maximum
   }
   s_score[tid] = best; s_idx[tid] = best_i;
@@ -1057,10 +1057,10 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
   const int win = s_idx[0];
   if (tid == 0) { cand->score = win >= 0 ? s_score[0] : -1.0; cand->index = win >= 0 ? (long long)(first_index + (unsigned long long)win) : -1ll; }
   if (win < 0) return;
-  if (tid < 4) cand->metrics[tid] = O.metrics[(size_t)win * 4 + tid];
-  if (tid < EG_YEARS) { cand->n_run[tid] = O.n_run[(size_t)win * EG_YEARS + tid]; cand->n_def[tid] = O.n_def[(size_t)win * EG_YEARS + tid]; }
-  for (int i = tid; i < EG_RUN_CAP; i += 1024) cand->run_log[i] = O.run_log[(size_t)win * EG_RUN_CAP + i];
-  for (int i = tid; i < EG_DEF_CAP; i += 1024) cand->def_log[i] = O.def_log[(size_t)win * EG_DEF_CAP + i];
+  if (tid < 4) cand->metrics[tid] = O.metrics(win)[tid];
+  if (tid < EG_YEARS) { cand->n_run[tid] = O.n_run(win)[tid]; cand->n_def[tid] = O.n_def(win)[tid]; }
+  for (int i = tid; i < EG_RUN_CAP; i += 1024) cand->run_log[i] = O.run_log(win)[i];
+  for (int i = tid; i < EG_DEF_CAP; i += 1024) cand->def_log[i] = O.def_log(win)[i];
 }
 
 }  // namespace
