@@ -12,8 +12,6 @@
 #include <vector>
 
 #include "eg_internal.h"
-#define EG_DETPOW_QUAL static inline
-#include "eg_detpow.h"
 
 namespace eg {
 namespace {
@@ -267,22 +265,6 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
     }
     std::memcpy(h + snap::row_totals, tot, sizeof(tot));
   }
-  if (s->iterations_without_improvement > 500u) {   // sampling.rs:190-220 on the un-nudged rows
-    const double stagnation = std::fmin(double(s->iterations_without_improvement) / 1000.0, 3.0);
-    const double power = 1.0 + (2.0 * stagnation);
-    double* scaled = reinterpret_cast<double*>(h + snap::scaled);
-    double* totals = reinterpret_cast<double*>(h + snap::scaled_total);
-    uint8_t* perm = h + snap::scaled_perm;
-    for (int y = 0; y < EG_YEARS; ++y) {
-      const double* w = s->weights + y * EG_N_ACTIONS;
-      int order[EG_N_ACTIONS];
-      for (int a = 0; a < EG_N_ACTIONS; ++a) order[a] = a;
-      std::stable_sort(order, order + EG_N_ACTIONS, [&](int a, int b) { return w[a] > w[b]; });
-      double t = 0.0;
-      for (int i = 0; i < EG_N_ACTIONS; ++i) { scaled[y * 64 + i] = eg_detpow(w[order[i]], power); perm[y * 64 + i] = uint8_t(order[i]); t += scaled[y * 64 + i]; }
-      totals[y] = t;
-    }
-  }
   unsigned long long mask[26] = {0}, dmask[26] = {0};
   if (have_lists)
     for (int y = 0; y < EG_YEARS; ++y) {
@@ -293,6 +275,11 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   std::memcpy(h + snap::best_off, off, sizeof(off)); std::memcpy(h + snap::bestd_off, offd, sizeof(offd));
   if (have_lists) { std::memcpy(h + snap::best_actions, s->best_actions, size_t(off[26])); std::memcpy(h + snap::bestd_actions, s->best_deficit_actions, size_t(offd[26])); }
   EG_HIP(hipMemcpyAsync(c->d_snap, h, snap::total, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
+  if (s->iterations_without_improvement > 500u) {   // sampling.rs:190-220 on the un-nudged rows, built on the device
+    const double stagnation = std::fmin(double(s->iterations_without_improvement) / 1000.0, 3.0);
+    int lr = launch_stalled_tables(c->d_snap, 1.0 + (2.0 * stagnation), nullptr);
+    if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  }
   DevSnapshot& S = c->snap;
   S = DevSnapshot{};
   S.base = c->d_snap; S.has_cw = s->count_weights ? 1 : 0;

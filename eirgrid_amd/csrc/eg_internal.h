@@ -197,6 +197,7 @@ struct UpdateCandidate;
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream,
                    bool helper_waves);
+int launch_stalled_tables(uint8_t* d_snap, double power, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180), evaluated on the host

@@ -1027,6 +1027,32 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
+// Stalled sampler tables of a freshly uploaded snapshot (sampling.rs:190-220 on the un-nudged rows): per year the
+// weights in stable descending order raised to the power (shared eg_detpow), the permutation and the table-order sum.
+// One workgroup per year; runs on the stream right behind the snapshot copy.
+__global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base, double power) {
+  __shared__ double s_w[64], s_scaled[64];
+  const int y = blockIdx.x, lane = threadIdx.x;
+  const double* w = reinterpret_cast<const double*>(snap_base + snap::w) + y * EG_N_ACTIONS;
+  double* scaled = reinterpret_cast<double*>(snap_base + snap::scaled) + y * 64;
+  uint8_t* perm = snap_base + snap::scaled_perm + y * 64;
+  const double mine = lane < EG_N_ACTIONS ? w[lane] : 0.0;
+  s_w[lane] = mine;
+  __syncthreads();
+  if (lane < EG_N_ACTIONS) {
+    int rank = 0;
+    for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = s_w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
+    const double v = eg_detpow(mine, power);
+    s_scaled[rank] = v; scaled[rank] = v; perm[rank] = (uint8_t)lane;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double t = 0.0;
+    for (int i = 0; i < EG_N_ACTIONS; ++i) t += s_scaled[i];
+    reinterpret_cast<double*>(snap_base + snap::scaled_total)[y] = t;
+  }
+}
+
 // statistics of a finished batch without re-running it (same accumulation as the k_rollout epilogue)
 __global__ void __launch_bounds__(kWave) k_update_stats(DevOut O, DevSnapshot S, StatsParams P, uint32_t n, long long* stats) {
   const uint32_t e = blockIdx.x;
@@ -1081,6 +1107,10 @@ int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_
                  int32_t* d_out_cell, double* d_out_score, void* stream) {
   hipLaunchKernelGGL(k_place, dim3(1), dim3(kWave), 0, (hipStream_t)stream, t, gen_type, year_index, d_cells, n_extra,
                      d_out_cell, d_out_score);
+  return (int)hipGetLastError();
+}
+int launch_stalled_tables(uint8_t* d_snap, double power, void* stream) {
+  hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap, power);
   return (int)hipGetLastError();
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream) {
