@@ -251,19 +251,18 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   if (size_t(off[26]) > snap::kBestCap || size_t(offd[26]) > snap::kBestCap) { set_error("eg_upload_snapshot: best action lists too long"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipStreamSynchronize(nullptr));   // the pinned staging buffer may still feed the previous copy
   uint8_t* h = c->h_snap;
-  std::memcpy(h + snap::w, s->weights, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
-  std::memcpy(h + snap::dw, s->deficit_weights, sizeof(double) * EG_YEARS * EG_N_DEFICIT);
-  if (s->count_weights) std::memcpy(h + snap::cw, s->count_weights, sizeof(double) * EG_YEARS * EG_N_COUNTS);
-  {  // sampling.rs:182, :352-355, :406: the sums the samplers start from, folded in table order like the device does
-    double tot[EG_YEARS * 3];
+  {  // packed policy rows; sampling.rs:182, :352-355, :406: the sums the samplers start from, folded in table order
+    double* pol = reinterpret_cast<double*>(h + snap::pol);
+    std::memset(pol, 0, sizeof(double) * EG_YEARS * snap::kPolRow);
     for (int y = 0; y < EG_YEARS; ++y) {
+      double* row = pol + y * snap::kPolRow;
       double a = 0.0, b = 0.0, c2 = 0.0;
-      for (int i = 0; i < EG_N_ACTIONS; ++i) a += s->weights[y * EG_N_ACTIONS + i];
+      for (int i = 0; i < EG_N_ACTIONS; ++i) { row[i] = s->weights[y * EG_N_ACTIONS + i]; a += row[i]; }
+      for (int i = 0; i < EG_N_DEFICIT; ++i) row[snap::kPolDw + i] = s->deficit_weights[y * EG_N_DEFICIT + i];
       for (int i = 0; i < 14; ++i) b += s->deficit_weights[y * EG_N_DEFICIT + i];
-      if (s->count_weights) for (int i = 0; i < EG_N_COUNTS; ++i) c2 += s->count_weights[y * EG_N_COUNTS + i];
-      tot[3 * y] = a; tot[3 * y + 1] = b; tot[3 * y + 2] = c2;
+      if (s->count_weights) for (int i = 0; i < EG_N_COUNTS; ++i) { row[snap::kPolCw + i] = s->count_weights[y * EG_N_COUNTS + i]; c2 += row[snap::kPolCw + i]; }
+      row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b; row[snap::kPolTotCount] = c2;
     }
-    std::memcpy(h + snap::row_totals, tot, sizeof(tot));
   }
   unsigned long long mask[26] = {0}, dmask[26] = {0};
   if (have_lists)

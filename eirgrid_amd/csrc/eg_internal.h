@@ -116,15 +116,16 @@ struct DevTables {
 // Policy snapshot in HBM: one packed buffer (filled by one copy from pinned memory), fixed layout.
 namespace snap {
 constexpr size_t kBestCap = 4096;     // best_actions can hold every replay-doubled year list
-constexpr size_t w = 0;                                                     // [26][61]
-constexpr size_t dw = w + 8 * EG_YEARS * EG_N_ACTIONS;                      // [26][15]
-constexpr size_t cw = dw + 8 * EG_YEARS * EG_N_DEFICIT;                     // [26][21] (has_cw)
-constexpr size_t row_totals = cw + 8 * EG_YEARS * EG_N_COUNTS;              // [26][3] sums of the w / dw (first 14) / cw rows
+// One 128-double block per year carries everything the episode wave loads into LDS at the start of that year:
+//   [0,61) main weights   [61] their table-order sum   [62] sum of the first 14 deficit weights   [63] sum of the count row
+//   [64,79) deficit weights   [79] stalled sampler: sum of the powered weights (written by k_stalled_tables)
+//   [80,101) action-count weights (has_cw)   [101,128) zero
+constexpr int kPolRow = 128, kPolTotMain = 61, kPolTotDeficit = 62, kPolTotCount = 63, kPolDw = 64, kPolScaledTotal = 79, kPolCw = 80;
+constexpr size_t pol = 0;                                                   // f64 [26][128]
 // stalled sampler (sampling.rs:190-220, stall > 500): per year the weights raised to the power in stable descending
-// order, the permutation and the sum, evaluated on the host with the shared eg_detpow; valid until the first nudge
-constexpr size_t scaled = row_totals + 8 * EG_YEARS * 3;                    // [26][64]
-constexpr size_t scaled_total = scaled + 8 * EG_YEARS * 64;                 // [26]
-constexpr size_t scaled_perm = scaled_total + 8 * EG_YEARS;                 // u8 [26][64]
+// order and the permutation, evaluated on the device with the shared eg_detpow; valid until the first nudge
+constexpr size_t scaled = pol + 8 * EG_YEARS * kPolRow;                     // [26][64]
+constexpr size_t scaled_perm = scaled + 8 * EG_YEARS * 64;                  // u8 [26][64]
 constexpr size_t best_mask = scaled_perm + 64 * EG_YEARS;                   // u64 [26] bit a: a occurs in best(y) or best_deficit(y)
 constexpr size_t bestd_mask = best_mask + 8 * EG_YEARS;                     // u64 [26] bit a: a occurs in best_deficit(y)
 constexpr size_t best_off = bestd_mask + 8 * EG_YEARS;                      // i32 [27(+1)] prefix offsets into best_actions
@@ -148,8 +149,7 @@ struct DevSnapshot {
   int32_t enable_energy_sales;
   int32_t write_yearly;
 #define EG_SNAP(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + snap::name); }
-  EG_SNAP(w, double) EG_SNAP(dw, double) EG_SNAP(cw, double) EG_SNAP(row_totals, double)
-  EG_SNAP(scaled, double) EG_SNAP(scaled_total, double) EG_SNAP(scaled_perm, uint8_t)
+  EG_SNAP(pol, double) EG_SNAP(scaled, double) EG_SNAP(scaled_perm, uint8_t)
   EG_SNAP(best_mask, unsigned long long) EG_SNAP(bestd_mask, unsigned long long)
   EG_SNAP(best_off, int32_t) EG_SNAP(bestd_off, int32_t) EG_SNAP(best_actions, uint8_t) EG_SNAP(bestd_actions, uint8_t)
 #undef EG_SNAP

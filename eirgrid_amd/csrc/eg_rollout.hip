@@ -48,9 +48,7 @@ struct __align__(16) Smem {
   double yr[9][EG_YEARS];             // per-year scalars: pre_co2, pre_tg, pre_ig, pre_sg, pre_optot, usage, population,
                                       // inflation, carbon_price
   int yr_opcnt[EG_YEARS];
-  double w[64];                       // this year's main weights (61 used)
-  double dw[16];                      // this year's deficit weights (15 used)
-  double cw[24];                      // this year's action-count weights (21 used)
+  double pol[snap::kPolRow];          // this year's policy row block (layout: eg_internal.h, namespace snap)
   uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
   uint32_t rng_key[8];                // ChaCha12 key of the episode stream
   unsigned long long rng_counter;     // next block counter
@@ -68,6 +66,9 @@ static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
+#define SM_W (sm.pol)                      // main weights [61]
+#define SM_DW (sm.pol + snap::kPolDw)      // deficit weights [15]
+#define SM_CW (sm.pol + snap::kPolCw)      // action-count weights [21]
 
 // A workgroup is ONE wavefront, and a wave's LDS operations execute in program order, so data written to LDS by one
 // lane is visible to every lane's later reads without waiting; what is needed is only that the compiler keeps the
@@ -437,13 +438,13 @@ __device__ void update_weights(const DevSnapshot& S, int lane, int action, doubl
   const double adj = combined > 0.0 ? 1.0 + (S.learning_rate * combined)
                                     : 1.0 / (1.0 + (S.learning_rate * dabs(combined)));
   wave_sync();
-  if (lane == 0) sm.w[action] = dmin(dmax(sm.w[action] * adj, kMinWeight), kMaxWeight);
+  if (lane == 0) SM_W[action] = dmin(dmax(SM_W[action] * adj, kMinWeight), kMaxWeight);
   wave_sync();
   if (combined < 0.0) {
     const double boost = 1.0 + (S.learning_rate * 0.1);
-    if (lane < kFirstOffset && lane != action) sm.w[lane] = dmin(sm.w[lane] * boost, kMaxWeight);
+    if (lane < kFirstOffset && lane != action) SM_W[lane] = dmin(SM_W[lane] * boost, kMaxWeight);
     wave_sync();
-    if (S.noop_boost && lane == 0) sm.w[kNothing] = dmin(sm.w[kNothing] * (1.0 + S.learning_rate * 0.2), kMaxWeight);
+    if (S.noop_boost && lane == 0) SM_W[kNothing] = dmin(SM_W[kNothing] * (1.0 + S.learning_rate * 0.2), kMaxWeight);
     wave_sync();
   }
 }
@@ -456,11 +457,11 @@ __device__ void update_deficit_weights(const DevSnapshot& S, int lane, int actio
   const double adj = improvement > 0.0 ? 1.0 + (S.learning_rate * improvement * 1.5)
                                        : 1.0 / (1.0 + (S.learning_rate * dabs(improvement) * 1.5));
   wave_sync();
-  if (lane == 0) sm.dw[slot] = dmin(dmax(sm.dw[slot] * adj, kMinWeight), kMaxWeight);
+  if (lane == 0) SM_DW[slot] = dmin(dmax(SM_DW[slot] * adj, kMinWeight), kMaxWeight);
   wave_sync();
   if (improvement < 0.0) {
     const double boost = 1.0 + (S.learning_rate * 0.1);
-    if (lane < 14 && lane != slot) sm.dw[lane] = dmin(sm.dw[lane] * boost, kMaxWeight);
+    if (lane < 14 && lane != slot) SM_DW[lane] = dmin(SM_DW[lane] * boost, kMaxWeight);
     wave_sync();
   }
 }
@@ -496,7 +497,7 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
   if (!tot.main_valid) {
     double t = 0.0;
 #pragma unroll 4
-    for (int a = 0; a < EG_N_ACTIONS; ++a) t += sm.w[a];
+    for (int a = 0; a < EG_N_ACTIONS; ++a) t += SM_W[a];
     tot.main = t; tot.main_valid = true;
   }
   const double total = tot.main;
@@ -507,10 +508,10 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
       const double power = 1.0 + (2.0 * stagnation);
       wave_sync();
       if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
-        const double mine = sm.w[lane];
+        const double mine = SM_W[lane];
         int rank = 0;
 #pragma unroll 4
-        for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = sm.w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
+        for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = SM_W[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
         sm.scaled[rank] = eg_detpow(mine, power);
         sm.ydef[128 + rank] = (uint8_t)lane;
       }
@@ -540,7 +541,7 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int a = a0 + u;
-      if (a < EG_N_ACTIONS) { v -= sm.w[a]; pick += v > 0.0 ? 1 : 0; }
+      if (a < EG_N_ACTIONS) { v -= SM_W[a]; pick += v > 0.0 ? 1 : 0; }
     }
     if (!(v > 0.0)) break;
   }
@@ -552,7 +553,7 @@ __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot
   if (!tot.deficit_valid) {
     double t = 0.0;
 #pragma unroll 7
-    for (int i = 0; i < 14; ++i) t += sm.dw[i];
+    for (int i = 0; i < 14; ++i) t += SM_DW[i];
     tot.deficit = t; tot.deficit_valid = true;
   }
   const double total = tot.deficit;
@@ -560,7 +561,7 @@ __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot
   double v = rng_f64(r, lane) * total;
   int pick = 0;
 #pragma unroll 7
-  for (int i = 0; i < 14; ++i) { v -= sm.dw[i]; pick += v > 0.0 ? 1 : 0; }
+  for (int i = 0; i < 14; ++i) { v -= SM_DW[i]; pick += v > 0.0 ? 1 : 0; }
   return pick < 14 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
 }
 
@@ -673,6 +674,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 #endif
 
   load_static_tables(T, lane);
+  // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
+  const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
+                                                 T.pre_tg()[lane] == T.pre_tg()[lane - 1] && T.pre_ig()[lane] == T.pre_ig()[lane - 1] &&
+                                                 T.pre_sg()[lane] == T.pre_sg()[lane - 1]);
   Rng rng;
   rng_seed(rng, seed + first_index + (unsigned long long)e, lane);   // simulation.rs:50-53, one stream per episode
   EG_MARKG(16);
@@ -690,30 +695,49 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
   if (lane < 8) sm.acc[lane] = 0.0;   // [0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row
 
-  double nw = lane < EG_N_ACTIONS ? S.w()[lane] : 0.0, ndw = lane < EG_N_DEFICIT ? S.dw()[lane] : 0.0;
-  double ncw = (S.has_cw && lane < EG_N_COUNTS) ? S.cw()[lane] : 0.0;
+  double np0 = S.pol()[lane], np1 = S.pol()[64 + lane];      // policy row block of year 0; later years are requested a year ahead
+  const bool stalled = S.stall > 500u;                        // stalled sampler tables travel the same way
+  double ns = 0.0; uint8_t nperm = 0;
+  if (stalled) { ns = S.scaled()[lane]; nperm = S.scaled_perm()[lane]; }
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
-    {  // this year's policy rows -> LDS (they were requested a year ahead: nw / ndw / ncw), then request next year's
     EG_MARKG(17);
+    // ---- requests first: the per-generator / per-offset terms of this year (first 64 of each list) ----
+    const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
+    const double* t12y = T.t12() + (size_t)yi * kTypes;
+    const double* offvy = T.offv() + (size_t)yi * kOffsetTypes * kYears;
+    const double* offcy = T.offc() + (size_t)yi * kOffsetTypes * kMults;
+    const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
+    const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
+    double2 g_cc = {0.0, 0.0}; double g_m03 = 0.0, g_t12 = 0.0, o_v = 0.0, o_c = 0.0; int g_t = 0;
+    if (ngen_s > 0) {
+      const bool valid = lane < ngen_s;
+      const int gc = valid ? sm.gcell[lane] : 0, bm = valid ? sm.gbm[lane] : 0;
+      const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
+      g_t = gc >> 12;
+      g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(g_t * kYears + b) * kMults + m) * 2);
+      g_m03 = T.m03()[cell]; g_t12 = t12y[g_t];
+    }
+    if (noff_s > 0) {
+      const int p = lane < noff_s ? sm.opack[lane] : 0;
+      const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+      o_v = offvy[ot * kYears + b]; o_c = offcy[ot * kMults + m];
+    }
+    {  // this year's policy block -> LDS (requested a year ahead), then request next year's
     wave_sync();
-    if (lane < EG_N_ACTIONS) sm.w[lane] = nw;
-    if (lane < EG_N_DEFICIT) sm.dw[lane] = ndw;
-    if (lane < EG_N_COUNTS) sm.cw[lane] = ncw;
-    if (S.stall > 500u) { sm.scaled[lane] = S.scaled()[yi * 64 + lane]; sm.ydef[128 + lane] = S.scaled_perm()[yi * 64 + lane]; }
+    sm.pol[lane] = np0; sm.pol[64 + lane] = np1;
+    if (stalled) { sm.scaled[lane] = ns; sm.ydef[128 + lane] = nperm; }
     if (yi + 1 < kYears) {
-      if (lane < EG_N_ACTIONS) nw = S.w()[(yi + 1) * EG_N_ACTIONS + lane];
-      if (lane < EG_N_DEFICIT) ndw = S.dw()[(yi + 1) * EG_N_DEFICIT + lane];
-      if (S.has_cw && lane < EG_N_COUNTS) ncw = S.cw()[(yi + 1) * EG_N_COUNTS + lane];
+      np0 = S.pol()[(yi + 1) * snap::kPolRow + lane]; np1 = S.pol()[(yi + 1) * snap::kPolRow + 64 + lane];
+      if (stalled) { ns = S.scaled()[(yi + 1) * 64 + lane]; nperm = S.scaled_perm()[(yi + 1) * 64 + lane]; }
     }
     wave_sync();
     EG_T1(5);
     }
-    EG_MARKG(18);
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
-    Totals tot; tot.main = S.row_totals()[3 * yi]; tot.deficit = S.row_totals()[3 * yi + 1]; tot.main_valid = true; tot.deficit_valid = true;
-    tot.scaled = S.stall > 500u ? S.scaled_total()[yi] : 0.0; tot.scaled_valid = true;
-    const double cw_total = S.row_totals()[3 * yi + 2];
+    Totals tot; tot.main = sm.pol[snap::kPolTotMain]; tot.deficit = sm.pol[snap::kPolTotDeficit]; tot.main_valid = true; tot.deficit_valid = true;
+    tot.scaled = sm.pol[snap::kPolScaledTotal]; tot.scaled_valid = true;
+    const double cw_total = sm.pol[snap::kPolTotCount];
     EG_TE(14);
 
     // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
@@ -728,19 +752,22 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     {
       EG_MARKG(18);
       const double pco2 = sm.yr[0][yi], ptg = sm.yr[1][yi], pig = sm.yr[2][yi], psg = sm.yr[3][yi];
-      const bool carry = yi > 0 && pco2 == sm.yr[0][yi - 1] && ptg == sm.yr[1][yi - 1] && pig == sm.yr[2][yi - 1] && psg == sm.yr[3][yi - 1];
+      const bool carry = ((carry_mask >> yi) & 1u) != 0u;
       if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
       else { a.co2 = pco2; a.tg = ptg; a.ig = pig; a.sg = psg; }
-      const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
-      const double* t12y = T.t12() + (size_t)yi * kTypes;
-      const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
       for (int base = 0; base < ngen_s; base += kWave) {
-        const int g = base + lane;
-        const bool valid = g < ngen_s;
-        const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
-        const int cell = gc & 0xFFF, t = gc >> 12, b = bm & 31, m = bm >> 5;
-        const double2 cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t * kYears + b) * kMults + m) * 2);
-        const double op = (T.m03()[cell] + t12y[t]) + cc.y;
+        if (base > 0) {      // beyond the first 64 generators (rare): same gather, inline
+          const int g = base + lane;
+          const bool valid = g < ngen_s;
+          const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
+          const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
+          g_t = gc >> 12;
+          g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(g_t * kYears + b) * kMults + m) * 2);
+          g_m03 = T.m03()[cell]; g_t12 = t12y[g_t];
+        }
+        const double2 cc = g_cc;
+        const int t = g_t;
+        const double op = (g_m03 + g_t12) + cc.y;
         double out = 0.0, co2 = 0.0; int cls = 0;
         if (!carry) { out = sm.type_out[t]; co2 = sm.type_co2[t]; cls = (sm.type_info[t] >> 12) & 3; }
         const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
@@ -764,14 +791,14 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         }
         a.opcnt += cnt;
       }
-      const double* offvy = T.offv() + (size_t)yi * kOffsetTypes * kYears;
-      const double* offcy = T.offc() + (size_t)yi * kOffsetTypes * kMults;
-      const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
       for (int base = 0; base < noff_s; base += kWave) {
-        const int k = base + lane;
-        const int p = k < noff_s ? sm.opack[k] : 0;
-        const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
-        const double ov = offvy[ot * kYears + b], oc = offcy[ot * kMults + m];
+        if (base > 0) {
+          const int k = base + lane;
+          const int p = k < noff_s ? sm.opack[k] : 0;
+          const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+          o_v = offvy[ot * kYears + b]; o_c = offcy[ot * kMults + m];
+        }
+        const double ov = o_v, oc = o_c;
         const int cnt = noff_s - base < kWave ? noff_s - base : kWave;
         for (int j = 0; j < cnt; ++j) { a.offs += readlane_f64(ov, j); a.ocost += readlane_f64(oc, j); }
       }
@@ -834,7 +861,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
             if (cap > 0u) {
               const double u = rng_f64(rng, lane);
               if (S.has_cw) {
-                const double* cw = sm.cw;
+                const double* cw = SM_CW;
                 const double total = cw_total;   // the count table is never nudged (Q3): its sum is a snapshot constant
                 if (total > 0.0) {
                   double v = u * total;
@@ -1033,7 +1060,8 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
 __global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base, double power) {
   __shared__ double s_w[64], s_scaled[64];
   const int y = blockIdx.x, lane = threadIdx.x;
-  const double* w = reinterpret_cast<const double*>(snap_base + snap::w) + y * EG_N_ACTIONS;
+  double* row = reinterpret_cast<double*>(snap_base + snap::pol) + y * snap::kPolRow;
+  const double* w = row;
   double* scaled = reinterpret_cast<double*>(snap_base + snap::scaled) + y * 64;
   uint8_t* perm = snap_base + snap::scaled_perm + y * 64;
   const double mine = lane < EG_N_ACTIONS ? w[lane] : 0.0;
@@ -1049,7 +1077,7 @@ __global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base, do
   if (lane == 0) {
     double t = 0.0;
     for (int i = 0; i < EG_N_ACTIONS; ++i) t += s_scaled[i];
-    reinterpret_cast<double*>(snap_base + snap::scaled_total)[y] = t;
+    row[snap::kPolScaledTotal] = t;
   }
 }
 

@@ -90,7 +90,10 @@ class ActionWeights:
 
     def __del__(self):
         if getattr(self, "h", None):
-            N.lib().eg_policy_free(self.h)
+            try:
+                N.lib().eg_policy_free(self.h)
+            except TypeError:      # interpreter shutdown: module globals are already gone
+                pass
             self.h = None
 
     def tables(self):
