@@ -67,6 +67,8 @@ struct eg_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double total_ms = 0.0; int32_t n_launches = 0;
   bool timing_pending = false;
+  // eg_train_step: library-owned update packet (device) and its pinned host copy
+  uint8_t* d_packet = nullptr; uint8_t* h_packet = nullptr;
   // batches of at most this many episodes run the helper-wave kernel (three waves per episode, all resident at once)
   uint32_t helper_max_episodes = 0;
 };
@@ -209,6 +211,8 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_snap) (void)hipFree(c->d_snap);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->d_mask) (void)hipFree(c->d_mask);
+  if (c->d_packet) (void)hipFree(c->d_packet);
+  if (c->h_packet) (void)hipHostFree(c->h_packet);
   free_outputs(c);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -382,6 +386,26 @@ int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
   EG_GET(n_draws, 1, uint64_t);
 #undef EG_GET
   return EG_OK;
+}
+
+int32_t eg_train_step(eg_ctx* c, eg_policy* p, const eg_opts* o, uint64_t seed, uint64_t first_index, uint32_t n,
+                      const uint8_t* replay_mask, uint64_t noise_seed) {
+  if (!c || !p) { set_error("eg_train_step: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  if (!c->d_packet) {
+    EG_HIP(hipMalloc((void**)&c->d_packet, EG_PACKET_BYTES));
+    EG_HIP(hipHostMalloc((void**)&c->h_packet, EG_PACKET_BYTES));
+  }
+  eg_policy_snapshot snap;
+  int rc = eg_policy_snapshot_view(p, &snap);
+  if (rc != EG_OK) return rc;
+  rc = eg_upload_snapshot(c, &snap, o);
+  if (rc != EG_OK) return rc;
+  rc = eg_rollout_launch_update(c, seed, first_index, n, replay_mask, c->d_packet);
+  if (rc != EG_OK) return rc;
+  EG_HIP(hipMemcpyAsync(c->h_packet, c->d_packet, EG_PACKET_BYTES, hipMemcpyDeviceToHost, nullptr));
+  EG_HIP(hipStreamSynchronize(nullptr));
+  return eg_policy_apply_packet(p, reinterpret_cast<const int64_t*>(c->h_packet), c->h_packet + 8 * EG_STATS_LEN, 1, noise_seed);
 }
 
 int32_t eg_rollout_batch(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o, uint64_t seed, uint64_t first_index,

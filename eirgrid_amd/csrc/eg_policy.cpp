@@ -326,4 +326,21 @@ int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double
   return improved ? 1 : EG_OK;
 }
 
+int32_t eg_policy_apply_packet(eg_policy* p, const int64_t* stats, const void* candidates, int32_t n_candidates, uint64_t noise_seed) {
+  if (!p || !stats || n_candidates < 0 || (n_candidates > 0 && !candidates)) return EG_ERR_BAD_ARG;
+  const uint8_t* win = nullptr; double win_score = 0.0; int64_t win_index = 0;
+  for (int r = 0; r < n_candidates; ++r) {
+    const uint8_t* c = static_cast<const uint8_t*>(candidates) + size_t(r) * EG_CANDIDATE_BYTES;
+    double score; int64_t index;
+    std::memcpy(&score, c, 8); std::memcpy(&index, c + 8, 8);
+    if (index < 0) continue;
+    if (!win || score > win_score || (score == win_score && index < win_index)) { win = c; win_score = score; win_index = index; }
+  }
+  if (!win) return eg_policy_apply_reduced(p, stats, nullptr, nullptr, nullptr, nullptr, nullptr, noise_seed);
+  double metrics[4]; int32_t n_run[EG_YEARS], n_def[EG_YEARS];
+  std::memcpy(metrics, win + 16, 32); std::memcpy(n_run, win + 48, 4 * EG_YEARS); std::memcpy(n_def, win + 48 + 4 * EG_YEARS, 4 * EG_YEARS);
+  const uint8_t* run_log = win + 48 + 8 * EG_YEARS; const uint8_t* def_log = run_log + EG_RUN_CAP;
+  return eg_policy_apply_reduced(p, stats, metrics, n_run, run_log, n_def, def_log, noise_seed);
+}
+
 }  // extern "C"

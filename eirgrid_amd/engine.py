@@ -157,6 +157,18 @@ def apply_reduced(weights: "ActionWeights", stats, candidate, noise_seed: int = 
     return rc == 1
 
 
+def apply_packet(weights: "ActionWeights", stats, candidates, noise_seed: int = 0) -> bool:
+    """eg_policy_apply_packet: `stats` int64[STATS_LEN] (all-reduced), `candidates` uint8[W, CANDIDATE_BYTES] candidate
+    records, one per rank.  The winner (highest score, ties to the lowest global index) competes for the best slot."""
+    st = np.ascontiguousarray(stats, dtype=np.int64)
+    cd = np.ascontiguousarray(candidates, dtype=np.uint8).reshape(-1, N.CANDIDATE_BYTES)
+    assert st.shape == (N.STATS_LEN,)
+    rc = N.lib().eg_policy_apply_packet(weights.h, st.ctypes.data, cd.ctypes.data, cd.shape[0], C.c_uint64(noise_seed))
+    if rc < 0:
+        N.check(rc, "eg_policy_apply_packet")
+    return rc == 1
+
+
 def score_metrics(metrics, cost_only: bool = False) -> float:
     m = np.ascontiguousarray(metrics, dtype=np.float64)
     return N.lib().eg_score_metrics(_p(m, C.c_double), int(cost_only))
@@ -268,6 +280,20 @@ class Engine:
             mask = _p(self._mask, C.c_uint8)
         N.check(N.lib().eg_rollout_launch_update(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index),
                                                  n_episodes, mask, C.c_void_p(d_packet_ptr)), "eg_rollout_launch_update")
+
+    def train_step(self, weights: ActionWeights, seed: int, first_episode_index: int, n_episodes: int, replay_mask=None,
+                   noise_seed: int = 0, enable_energy_sales=True, write_yearly=True) -> bool:
+        """eg_train_step: the whole single-GPU training step in one library call.  Returns True on a new best strategy."""
+        mask = None
+        if replay_mask is not None:
+            self._mask = np.ascontiguousarray(replay_mask, dtype=np.uint8)
+            mask = _p(self._mask, C.c_uint8)
+        opts = self._opts(enable_energy_sales, False, write_yearly)
+        rc = N.lib().eg_train_step(self.h, weights.h, C.byref(opts), C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index),
+                                   n_episodes, mask, C.c_uint64(noise_seed & (2**64 - 1)))
+        if rc < 0:
+            N.check(rc, "eg_train_step")
+        return rc == 1
 
     def sync(self):
         N.check(N.lib().eg_sync(self.h), "eg_sync")

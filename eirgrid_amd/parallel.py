@@ -13,7 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native as N
-from .engine import ActionWeights, Engine, apply_reduced
+from .engine import ActionWeights, Engine, apply_packet, apply_reduced
 
 
 def shard_range(total: int, rank: int, world_size: int):
@@ -63,16 +63,16 @@ def parse_candidate(buf: np.ndarray):
     return score, index, unpack_candidate(buf[16:])
 
 
-def exchange_packet(packet, dist=None):
+def exchange_packet_raw(packet, dist=None):
     """The whole per-update exchange on an update packet (torch uint8 tensor [PACKET_BYTES] on the device):
-    ONE sum all-reduce of the int64 statistics part + an all-gather of the per-rank candidate records (3.3 KB each).
-    Returns (stats ndarray, candidate tuple | None); every rank computes the same result."""
+    ONE sum all-reduce of the int64 statistics part + an all-gather of the per-rank candidate records (3.3 KB each),
+    then ONE copy to the host.  Returns (stats int64 ndarray [STATS_LEN], candidates uint8 ndarray [W, CANDIDATE_BYTES]),
+    the inputs of eg_policy_apply_packet; every rank holds the same data."""
     import torch
     nstat = 8 * N.STATS_LEN
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         host = packet.cpu().numpy()
-        score, index, cand = parse_candidate(host[nstat:])
-        return host[:nstat].view(np.int64).copy(), (cand if index >= 0 else None)
+        return host[:nstat].view(np.int64).copy(), host[nstat:].reshape(1, N.CANDIDATE_BYTES)
     ws = dist.get_world_size()
     if dist.get_backend() == "gloo":          # CPU rehearsal of the same exchange (tests; no RCCL involved)
         host = packet.cpu()
@@ -81,18 +81,22 @@ def exchange_packet(packet, dist=None):
         mine = host[nstat:].clone()
         gathered = [torch.empty_like(mine) for _ in range(ws)]
         dist.all_gather(gathered, mine)
-        host_stats = stats.numpy().copy()
-        host_cands = torch.stack(gathered).numpy()
-    else:
-        stats = packet[:nstat].view(torch.int64)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)                # the one all-reduce of the update (RCCL over xGMI)
-        cands = torch.empty(ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
-        dist.all_gather_into_tensor(cands, packet[nstat:].contiguous())
-        host_stats = stats.cpu().numpy().copy()
-        host_cands = cands.cpu().numpy().reshape(ws, N.CANDIDATE_BYTES)
-    parsed = [parse_candidate(host_cands[r]) for r in range(ws)]
+        return stats.numpy().copy(), torch.stack(gathered).numpy()
+    stats = packet[:nstat].view(torch.int64)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)                # the one all-reduce of the update (RCCL over xGMI)
+    both = torch.empty(nstat + ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
+    dist.all_gather_into_tensor(both[nstat:], packet[nstat:].contiguous())
+    both[:nstat] = packet[:nstat]
+    host = both.cpu().numpy()                                   # one device-to-host copy
+    return host[:nstat].view(np.int64).copy(), host[nstat:].reshape(ws, N.CANDIDATE_BYTES)
+
+
+def exchange_packet(packet, dist=None):
+    """exchange_packet_raw with the winning candidate already parsed: (stats ndarray, candidate tuple | None)."""
+    stats, cands = exchange_packet_raw(packet, dist)
+    parsed = [parse_candidate(cands[r]) for r in range(cands.shape[0])]
     win = pick_candidate([(p[0], p[1]) for p in parsed])
-    return host_stats, (parsed[win[0]][2] if win is not None else None)
+    return stats, (parsed[win[0]][2] if win is not None else None)
 
 
 def exchange_update(stats, local_pair, local_payload_fn, dist=None, device=None):
@@ -145,10 +149,14 @@ class BatchTrainer:
         if self.replay_fraction > 0.0 and self.w.get("has_best_actions") == 1:
             period = max(1, int(round(1.0 / self.replay_fraction)))
             mask = ((np.arange(first, first + self.n) % period) == 0).astype(np.uint8)
-        self.eng.upload_snapshot(self.w, write_yearly=self.write_yearly)
-        self.eng.launch_update(self.seed, first, self.n, self.packet.data_ptr(), mask)   # rollout + stats + best pick
-        stats, cand = exchange_packet(self.packet, self.dist)                             # all-reduce + one D2H copy
-        improved = apply_reduced(self.w, stats, cand, noise_seed=self.seed + self.step_index)
+        noise = self.seed + self.step_index
+        if self.dist is None or self.ws == 1:      # one GPU: the whole step is one library call
+            improved = self.eng.train_step(self.w, self.seed, first, self.n, mask, noise_seed=noise, write_yearly=self.write_yearly)
+        else:
+            self.eng.upload_snapshot(self.w, write_yearly=self.write_yearly)
+            self.eng.launch_update(self.seed, first, self.n, self.packet.data_ptr(), mask)   # rollout + stats + best pick
+            stats, cands = exchange_packet_raw(self.packet, self.dist)                        # all-reduce + one D2H copy
+            improved = apply_packet(self.w, stats, cands, noise_seed=noise)
         self.improvements += int(improved)
         self.step_index += 1
         return improved

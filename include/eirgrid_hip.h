@@ -212,6 +212,16 @@ int32_t eg_policy_apply_episode(eg_policy *, const double metrics[4], const int3
 int32_t eg_policy_apply_reduced(eg_policy *, const int64_t *stats, const double cand_metrics[4], const int32_t *cand_n_run,
                                 const uint8_t *cand_run_log, const int32_t *cand_n_def, const uint8_t *cand_def_log,
                                 uint64_t noise_seed);
+/* The same update from update packets: `stats` = the (all-reduced) int64[EG_STATS_LEN] statistics, `candidates` =
+ * n_candidates candidate records of EG_CANDIDATE_BYTES each (one per rank, in rank order; layout above).  The winner is
+ * the record with the highest score, ties to the lowest global index (index < 0: no candidate).  Returns 1 when the
+ * winner became the best strategy, 0 when not, < 0 on error. */
+int32_t eg_policy_apply_packet(eg_policy *, const int64_t *stats, const void *candidates, int32_t n_candidates,
+                               uint64_t noise_seed);
+/* One whole pass of the batch training step on one GPU, one call: snapshot upload, rollout with the statistics
+ * epilogue, best pick, ONE packet copy to pinned host memory, eg_policy_apply_packet.  Same return convention. */
+int32_t eg_train_step(eg_ctx *, eg_policy *, const eg_opts *opts, uint64_t seed, uint64_t first_episode_index,
+                      uint32_t n_episodes, const uint8_t *replay_mask /* host, may be NULL */, uint64_t noise_seed);
 /* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */

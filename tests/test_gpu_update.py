@@ -155,3 +155,25 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["episodes_ok_last_batch"] == 256
+
+
+def test_train_step_equals_the_stepwise_path(engine):
+    """eg_train_step (one library call per step) == upload + launch_update + packet copy + apply, bit for bit."""
+    from eirgrid_amd.engine import apply_packet
+    from eirgrid_amd.parallel import exchange_packet_raw
+    a, b = ActionWeights(), ActionWeights()
+    packet = torch.zeros(N.PACKET_BYTES, dtype=torch.uint8, device="cuda")
+    n = 192
+    for step in range(5):
+        mask = ((np.arange(n) % 5) == 1).astype(np.uint8) if step > 0 else None
+        fa = engine.train_step(a, 99, step * n, n, mask, noise_seed=1000 + step)
+        engine.upload_snapshot(b)
+        engine.launch_update(99, step * n, n, packet.data_ptr(), mask)
+        stats, cands = exchange_packet_raw(packet)
+        fb = apply_packet(b, stats, cands, noise_seed=1000 + step)
+        assert fa == fb
+        for x, y in zip(a.tables(), b.tables()):
+            assert x.tobytes() == y.tobytes()
+        assert a.lists(0) == b.lists(0) and a.lists(1) == b.lists(1)
+        for name in ("iterations_without_improvement", "iteration_count", "has_best", "best_cost", "best_net_emissions"):
+            assert a.get(name) == b.get(name), name

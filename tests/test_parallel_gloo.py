@@ -89,3 +89,41 @@ def test_two_rank_exchange(built):
     assert a[6] == b[6] and a[7] == b[7]           # bit-identical replicas
     scores, metrics = a[8] + b[8], a[9] + b[9]
     assert a[3] == metrics[int(np.argmax(scores))]   # the winner is the global arg-max (np.argmax: lowest index on ties)
+
+
+def test_apply_packet_equals_pick_then_apply_reduced(built):
+    """eg_policy_apply_packet (C: winner by score, ties to the lowest global index) == pick_candidate + apply_reduced."""
+    import numpy as np
+    from eirgrid_amd import _native as N
+    from eirgrid_amd.engine import ActionWeights, apply_packet, apply_reduced
+    from eirgrid_amd.parallel import pack_candidate, parse_candidate, pick_candidate
+    rng = np.random.default_rng(11)
+    for trial in range(4):
+        stats = np.zeros(N.STATS_LEN, np.int64)
+        stats[0] = 40; stats[2] = 12
+        stats[8:8 + 2 * 26 * 61] = -rng.integers(0, 2**28, 2 * 26 * 61)
+        stats[8 + 2 * 26 * 61:] = rng.integers(0, 5, 26 * 15)
+        recs = np.zeros((3, N.CANDIDATE_BYTES), np.uint8)
+        scores = [0.41, 0.77, 0.77] if trial % 2 == 0 else [0.2, 0.1, 0.3]
+        index = [5, 90, 31] if trial < 3 else [-1, -1, -1]
+        for r in range(3):
+            nr = rng.integers(0, 4, 26).astype(np.int32); nd = rng.integers(0, 3, 26).astype(np.int32)
+            rl = np.zeros(N.RUN_CAP, np.uint8); rl[:int(nr.sum())] = rng.integers(0, 61, int(nr.sum()))
+            dl = np.zeros(N.DEF_CAP, np.uint8); dl[:int(nd.sum())] = 3 * rng.integers(0, 15, int(nd.sum()))
+            metrics = [-1000.0 * (r + 1), 0.7, 3e10 / (1.0 + scores[r]), 1.0]
+            recs[r, 0:8] = np.array([scores[r]], np.float64).view(np.uint8)
+            recs[r, 8:16] = np.array([index[r]], np.int64).view(np.uint8)
+            recs[r, 16:] = pack_candidate(metrics, nr, rl, nd, dl)
+        a, b = ActionWeights(), ActionWeights()
+        for pol in (a, b):     # a best strategy must exist for the contrast step to do anything
+            pol.apply_episode([5e5, 0.6, 9e11, 1.0], np.ones(26, np.int32), np.full(26, 60, np.uint8), np.zeros(26, np.int32), np.zeros(0, np.uint8))
+        parsed = [parse_candidate(recs[r]) for r in range(3)]
+        win = pick_candidate([(p[0], p[1]) for p in parsed])
+        fa = apply_packet(a, stats, recs, noise_seed=trial)
+        fb = apply_reduced(b, stats, parsed[win[0]][2] if win else None, noise_seed=trial)
+        assert fa == fb
+        if trial == 0:
+            assert win[0] == 2          # tie on the score: the lower global index wins
+        for x, y in zip(a.tables(), b.tables()):
+            assert x.tobytes() == y.tobytes()
+        assert a.lists(0) == b.lists(0) and a.get("iterations_without_improvement") == b.get("iterations_without_improvement")
