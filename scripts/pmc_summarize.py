@@ -13,7 +13,7 @@ def rows(d, counter):
     out = []
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and "k_rollout(" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("k_rollout(" in r["Kernel_Name"] or "k_rollout<" in r["Kernel_Name"]):
                 out.append(dict(dispatch=int(r["Dispatch_Id"]), grid=int(r["Grid_Size"]), value_kb=float(r["Counter_Value"]),
                                 dur_ns=int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), vgpr=int(r["VGPR_Count"]),
                                 lds=int(r["LDS_Block_Size"])))
