@@ -61,6 +61,9 @@ struct __align__(16) Smem {
   int cmd[2][2];                      // {year | variant << 8 | radius class << 12 (or -1: exit), generators in the list}
   uint32_t hflag[2];                  // sequence number of the search whose result is in hres[h]
   struct { double score, m03; int cell, pad; } hres[2];
+#ifdef EG_STAMPS
+  unsigned long long hdbg[2][4];
+#endif
 };
 static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
 
@@ -342,9 +345,22 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     if (c0 < 0) return;
     const int yi = c0 & 31, v = (c0 >> 8) & 15, rc = (c0 >> 12) & 15;
     const int r = h * kWave + lane;
+#ifdef EG_STAMPS
+    const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
     const PsRec c = T.ps()[(size_t)(yi * kMaxVariants + v) * kPsStride + r];
+#ifdef EG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long th1 = __builtin_readcyclecounter();
+#endif
     const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell);
+#ifdef EG_STAMPS
+    const unsigned long long th2 = __builtin_readcyclecounter();
+#endif
     const ChunkBest b = chunk_reduce(s, (int)c.cell, c.m03);
+#ifdef EG_STAMPS
+    if (lane == 0) { sm.hdbg[h - 1][0] = th1 - th0; sm.hdbg[h - 1][1] = th2 - th1; sm.hdbg[h - 1][2] = __builtin_readcyclecounter() - th2; }
+#endif
     if (lane == 0) { sm.hres[h - 1].score = b.score; sm.hres[h - 1].m03 = b.m03; sm.hres[h - 1].cell = b.cell; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) *(volatile uint32_t*)&sm.hflag[h - 1] = sq;
@@ -388,8 +404,14 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (b0.score > 0.0) { best = b0.score; best_c = b0.cell; m03w = b0.m03; }
     for (int h = 1; h <= kHelpers && more; ++h) {
       if (!(readlane_f64(bound, h - 1) >= best)) { more = false; break; }
+#ifdef EG_STAMPS
+      const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
       while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[h - 1]) != (int)sq) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
+#ifdef EG_STAMPS
+      if (stamps) { stamps[6] += __builtin_readcyclecounter() - tw0; stamps[27] += sm.hdbg[h - 1][0]; stamps[28] += sm.hdbg[h - 1][1]; stamps[29] += sm.hdbg[h - 1][2]; stamps[30] += 1; }
+#endif
       const double hs = sm.hres[h - 1].score; const int hc = sm.hres[h - 1].cell;
       if (hs > best || (hs == best && hs > 0.0 && hc < best_c)) { best = hs; best_c = hc; m03w = sm.hres[h - 1].m03; }
 #ifdef EG_STAMPS

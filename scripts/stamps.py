@@ -12,7 +12,7 @@ eng.upload_snapshot(pol, write_yearly=(os.environ.get('EG_NO_YEARLY') is None));
 res = eng.fetch(B)
 st = res.act_log[:, -256:].copy().view(np.uint64).astype(np.float64)   # [B, 32]
 names = {0: "year-start aggregates", 1: "placement search", 2: "sampling (rng + walks)", 3: "deficit evaluate + nudges",
-         4: "yearly metrics + stores", 5: "policy rows -> LDS", 6: "glue (unnamed)", 12: "apply: generator bookkeeping",
+         4: "yearly metrics + stores", 5: "policy rows -> LDS", 6: "(inside placement) spin on helper flags", 12: "apply: generator bookkeeping",
          13: "apply: offset", 14: "year: totals scalars", 15: "year: initial state", 16: "episode start (tables, seed)",
          17: "glue: year loop back edge", 18: "glue: before aggregates", 19: "glue: loop top -> sampling",
          20: "glue: sampled -> search/offset", 21: "glue: search -> bookkeeping", 22: "glue: apply -> evaluate (logs)",
@@ -28,4 +28,6 @@ print(f"  placement detail: searches/ep {st[:, 11].mean():.1f}  chunks/search {s
       f"generator loop {st[:, 9].mean():.0f} cyc/ep ({st[:, 9].sum() / st[:, 8].sum():.0f}/chunk)  reduce+select {st[:, 10].mean():.0f} cyc/ep ({st[:, 10].sum() / st[:, 8].sum():.0f}/chunk)  "
       f"rest (loads, setup, exit test) {(st[:, 1] - st[:, 9] - st[:, 10]).mean():.0f} cyc/ep")
 k = int(np.argmax(st[:, 7]))
+nm = st[:, 30].sum()
+print(f"  helper results merged/ep {st[:, 30].mean():.1f}: episode wave spun {st[:, 6].sum() / nm:.0f} cyc per merge; helper per chunk: load wait {st[:, 27].sum() / nm:.0f}, score {st[:, 28].sum() / nm:.0f}, reduce {st[:, 29].sum() / nm:.0f}")
 print(f"  slowest episode {k}: total {st[k, 7]:.0f}, placement {st[k, 1]:.0f}, searches {st[k, 11]:.0f}, chunks {st[k, 8]:.0f}, gens {res.n_gens[k]}, year-start {st[k, 0]:.0f}, sampling {st[k, 2]:.0f}")
