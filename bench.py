@@ -158,6 +158,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    trainer.sync()                     # device-resident policy -> host copy (after the timed region)
     kernel_ms, n_launch = eng.timing_read()
     res = eng.fetch(args.episodes)
     ok = int((res.status == 0).sum())

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "eg_internal.h"
+#include "eg_policy_internal.h"
+#define EG_RM static inline
+#include "eg_reduced_math.h"
 
 namespace eg {
 namespace {
@@ -56,7 +59,6 @@ struct eg_ctx {
   // snapshot in HBM
   // the whole snapshot lives in ONE device buffer filled by ONE copy from a pinned staging buffer
   uint8_t* d_snap = nullptr; uint8_t* h_snap = nullptr;
-  StatsParams stats_params{};
   DevSnapshot snap{};
   bool snap_valid = false;
   // outputs
@@ -67,7 +69,9 @@ struct eg_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double total_ms = 0.0; int32_t n_launches = 0;
   bool timing_pending = false;
-  // eg_train_step: library-owned update packet (device) and its pinned host copy
+  uint32_t push_iteration_count = 0;     // iteration counter written into the device state by the next upload
+  uint32_t pulled_improvements = 0;      // on-device improvement log entries already appended to a host policy
+  // eg_train_step / eg_device_step: library-owned update packet (device) and its pinned host copy
   uint8_t* d_packet = nullptr; uint8_t* h_packet = nullptr;
   // batches of at most this many episodes run the helper-wave kernel (three waves per episode, all resident at once)
   uint32_t helper_max_episodes = 0;
@@ -277,36 +281,23 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   std::memcpy(h + snap::best_mask, mask, sizeof(mask)); std::memcpy(h + snap::bestd_mask, dmask, sizeof(dmask));
   std::memcpy(h + snap::best_off, off, sizeof(off)); std::memcpy(h + snap::bestd_off, offd, sizeof(offd));
   if (have_lists) { std::memcpy(h + snap::best_actions, s->best_actions, size_t(off[26])); std::memcpy(h + snap::bestd_actions, s->best_deficit_actions, size_t(offd[26])); }
-  EG_HIP(hipMemcpyAsync(c->d_snap, h, snap::total, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
-  if (s->iterations_without_improvement > 500u) {   // sampling.rs:190-220 on the un-nudged rows, built on the device
-    const double stagnation = std::fmin(double(s->iterations_without_improvement) / 1000.0, 3.0);
-    int lr = launch_stalled_tables(c->d_snap, 1.0 + (2.0 * stagnation), nullptr);
+  {  // the policy's scalars as the kernels read them (snap::state)
+    DevState st{};
+    st.learning_rate = s->learning_rate; st.exploration_rate = s->exploration_rate;
+    for (int i = 0; i < 4; ++i) st.best_metrics[i] = s->has_best ? s->best_metrics[i] : 0.0;
+    st.stall = s->iterations_without_improvement; st.iteration_count = c->push_iteration_count;
+    st.has_best = s->has_best ? 1 : 0; st.has_cw = s->count_weights ? 1 : 0; st.has_lists = have_lists ? 1 : 0;
+    rm::derive_state(st);
+    std::memcpy(h + snap::state, &st, sizeof(st));
+  }
+  EG_HIP(hipMemcpyAsync(c->d_snap, h, snap::upload_bytes, hipMemcpyHostToDevice, nullptr));   // stream-ordered before the next launch
+  {
+    int lr = launch_stalled_tables(c->d_snap, nullptr);      // sampling.rs:190-220 on the un-nudged rows (no-op unless stalled)
     if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   }
   DevSnapshot& S = c->snap;
   S = DevSnapshot{};
-  S.base = c->d_snap; S.has_cw = s->count_weights ? 1 : 0;
-  S.learning_rate = s->learning_rate; S.exploration_rate = s->exploration_rate; S.stall = s->iterations_without_improvement;
-  S.has_best = s->has_best ? 1 : 0;
-  // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)
-  const double final_impact = s->has_best ? eg_score_metrics(s->best_metrics, 0) : 0.0;
-  double rel = final_impact;
-  if (s->has_best) { const double best_score = eg_score_metrics(s->best_metrics, 0); rel = best_score > 0.0 ? (final_impact - best_score) / best_score : final_impact; }
-  S.rel_improvement = rel; S.immediate_weight = rel > 0.0 ? 0.7 : 0.3;
-  S.noop_boost = (s->has_best && s->best_metrics[0] <= 0.0 && s->best_metrics[2] > 50000000000.0 * 8.0) ? 1 : 0;   // learning.rs:82
-  const double scaled = std::pow(s->exploration_rate, 0.5);   // sampling.rs:425-427
-  S.heur_min = uint32_t(std::round(2.0 / scaled)); S.heur_max = uint32_t(std::round(12.0 / scaled));
-  S.has_best_actions = have_lists ? 1 : 0; S.has_best_deficit = have_lists ? 1 : 0;
-  {  // learning.rs:134-180: everything of the contrast step that depends only on the snapshot
-    StatsParams& P = c->stats_params;
-    const double k = double(s->iterations_without_improvement);
-    P.has_best = have_lists ? 1 : 0;
-    P.best_score = s->has_best ? eg_score_metrics(s->best_metrics, 0) : 0.0;
-    P.threshold = 0.1 * std::fmax(std::exp(-k / 500.0), 0.00001 / 0.1);
-    P.forced = s->iterations_without_improvement > 800u ? 1 : 0;
-    P.stagnation = 1.0 + (0.2 * std::pow(k / 10.0, 1.8));
-    P.adaptive_lr = s->learning_rate * (1.0 + 0.1 * k);
-  }
+  S.base = c->d_snap;
   S.enable_energy_sales = o ? (o->enable_energy_sales ? 1 : 0) : 1;
   S.write_yearly = o ? (o->write_yearly ? 1 : 0) : 1;
   c->snap_valid = true;
@@ -328,7 +319,7 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
   EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, nullptr, nullptr, n <= c->helper_max_episodes);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
@@ -351,7 +342,7 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
   EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, c->stats_params, (long long*)d_packet, nullptr, n <= c->helper_max_episodes);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
@@ -408,6 +399,114 @@ int32_t eg_train_step(eg_ctx* c, eg_policy* p, const eg_opts* o, uint64_t seed, 
   return eg_policy_apply_packet(p, reinterpret_cast<const int64_t*>(c->h_packet), c->h_packet + 8 * EG_STATS_LEN, 1, noise_seed);
 }
 
+// ---- device-resident policy: push once, step without host synchronisation, pull when needed -----------------------
+namespace {
+int ensure_packet(eg_ctx* c) {
+  if (c->d_packet) return EG_OK;
+  EG_HIP(hipMalloc((void**)&c->d_packet, EG_PACKET_BYTES));
+  EG_HIP(hipHostMalloc((void**)&c->h_packet, EG_PACKET_BYTES));
+  return EG_OK;
+}
+}  // namespace
+
+int32_t eg_policy_push(eg_ctx* c, const eg_policy* p, const eg_opts* o) {
+  if (!c || !p) { set_error("eg_policy_push: bad argument"); return EG_ERR_BAD_ARG; }
+  eg_policy_snapshot snap;
+  int rc = eg_policy_snapshot_view(p, &snap);
+  if (rc != EG_OK) return rc;
+  c->push_iteration_count = p->iteration_count;
+  rc = eg_upload_snapshot(c, &snap, o);
+  c->push_iteration_count = 0;
+  if (rc != EG_OK) return rc;
+  c->pulled_improvements = 0;
+  rc = ensure_packet(c);
+  if (rc != EG_OK) return rc;
+  EG_HIP(hipMemsetAsync(c->d_packet, 0, EG_PACKET_BYTES, nullptr));
+  // main weights at the last improvement travel with the policy
+  if (p->has_best_weights) EG_HIP(hipMemcpyAsync(c->d_snap + snap::best_w, p->best_w.data(), sizeof(double) * EG_YEARS * EG_N_ACTIONS, hipMemcpyHostToDevice, nullptr));
+  EG_HIP(hipStreamSynchronize(nullptr));      // p->best_w is pageable host memory
+  return EG_OK;
+}
+
+int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, void* d_packet) {
+  if (!c || !c->snap_valid || !d_packet) { set_error("eg_device_rollout: push a policy first"); return EG_ERR_BAD_ARG; }
+  if (n == 0) { c->last_n = 0; return EG_OK; }
+  EG_HIP(hipSetDevice(c->device));
+  int rc = ensure_outputs(c, n);
+  if (rc != EG_OK) return rc;
+  rc = collect_timing(c);
+  if (rc != EG_OK) return rc;
+  EG_HIP(hipEventRecord(c->ev0, nullptr));
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, nullptr, replay_period, (long long*)d_packet, nullptr,
+                          n <= c->helper_max_episodes);
+  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  EG_HIP(hipEventRecord(c->ev1, nullptr));
+  c->timing_pending = true;
+  c->last_n = n;
+  lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
+  if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  return EG_OK;
+}
+
+int32_t eg_device_apply(eg_ctx* c, void* d_stats, const void* d_candidates, int32_t n_candidates, uint64_t noise_seed) {
+  if (!c || !c->snap_valid || !d_stats || n_candidates < 0 || (n_candidates > 0 && !d_candidates)) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  int lr = launch_apply_update(c->d_snap, (long long*)d_stats, d_candidates, n_candidates, noise_seed, nullptr);
+  if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  lr = launch_stalled_tables(c->d_snap, nullptr);
+  if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  return EG_OK;
+}
+
+int32_t eg_device_step(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, uint64_t noise_seed) {
+  if (!c) return EG_ERR_BAD_ARG;
+  int rc = ensure_packet(c);
+  if (rc != EG_OK) return rc;
+  rc = eg_device_rollout(c, seed, first_index, n, replay_period, c->d_packet);
+  if (rc != EG_OK) return rc;
+  return eg_device_apply(c, c->d_packet, c->d_packet + 8 * EG_STATS_LEN, 1, noise_seed);
+}
+
+int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
+  if (!c || !p || !c->snap_valid) { set_error("eg_policy_pull: push a policy first"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipStreamSynchronize(nullptr));
+  std::vector<uint8_t> h(snap::total);
+  EG_HIP(hipMemcpy(h.data(), c->d_snap, snap::total, hipMemcpyDeviceToHost));
+  const double* pol = reinterpret_cast<const double*>(h.data() + snap::pol);
+  DevState st; std::memcpy(&st, h.data() + snap::state, sizeof(st));
+  for (int y = 0; y < EG_YEARS; ++y) {
+    const double* row = pol + y * snap::kPolRow;
+    for (int a = 0; a < EG_N_ACTIONS; ++a) p->w[y][a] = row[a];
+    for (int i = 0; i < EG_N_DEFICIT; ++i) p->dw[y][i] = row[snap::kPolDw + i];
+  }
+  p->stall = st.stall; p->iteration_count = st.iteration_count;
+  if (st.n_improvements > c->pulled_improvements) {      // at least one on-device improvement since the last pull
+    p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = st.best_metrics[i];
+    const int32_t* off = reinterpret_cast<const int32_t*>(h.data() + snap::best_off);
+    const int32_t* offd = reinterpret_cast<const int32_t*>(h.data() + snap::bestd_off);
+    for (int y = 0; y < EG_YEARS; ++y) {
+      p->best_actions[y].assign(h.data() + snap::best_actions + off[y], h.data() + snap::best_actions + off[y + 1]);
+      p->best_deficit[y].assign(h.data() + snap::bestd_actions + offd[y], h.data() + snap::bestd_actions + offd[y + 1]);
+      p->cur_run[y] = p->best_actions[y]; p->cur_def[y] = p->best_deficit[y];
+    }
+    p->has_best_actions = true; p->has_best_deficit = true; p->has_best_weights = true;
+    std::memcpy(p->best_w.data(), h.data() + snap::best_w, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
+    const DevImprovement* log = reinterpret_cast<const DevImprovement*>(h.data() + snap::imp_log);
+    uint32_t from = c->pulled_improvements;
+    if (st.n_improvements - from > uint32_t(snap::kImpLogCap)) from = st.n_improvements - uint32_t(snap::kImpLogCap);   // ring overwrote older ones
+    const uint32_t keep = p->iteration_count;
+    for (uint32_t k = from; k < st.n_improvements; ++k) {
+      const DevImprovement& e = log[k % snap::kImpLogCap];
+      p->iteration_count = e.iteration;
+      p->record_improvement(e.score, e.metrics);
+    }
+    p->iteration_count = keep;
+    c->pulled_improvements = st.n_improvements;
+  }
+  return EG_OK;
+}
+
 int32_t eg_rollout_batch(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* o, uint64_t seed, uint64_t first_index,
                          uint32_t n, const uint8_t* replay_mask, eg_episode_out* out) {
   int rc = eg_upload_snapshot(c, s, o);
@@ -435,7 +534,7 @@ int32_t eg_update_stats(eg_ctx* c, int64_t* d_stats) {
   if (!c || !d_stats || !c->snap_valid) { set_error("eg_update_stats: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
   EG_HIP(hipMemsetAsync(d_stats, 0, sizeof(int64_t) * EG_STATS_LEN, nullptr));
-  int lr = launch_update_stats(c->snap, c->out, c->stats_params, c->last_n, (long long*)d_stats, nullptr);
+  int lr = launch_update_stats(c->snap, c->out, c->last_n, (long long*)d_stats, nullptr);
   if (lr != 0) { set_error(std::string("k_update_stats launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }

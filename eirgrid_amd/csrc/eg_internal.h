@@ -113,6 +113,23 @@ struct DevTables {
 #undef EG_TAB
 };
 
+// Scalars of the policy as the kernels see them.  They live in the snapshot buffer (snap::state), not in kernel
+// arguments: the host writes them at upload (eg_reduced_math.h derive_state), an on-device update rewrites them.
+struct DevState {
+  double learning_rate, exploration_rate;
+  double best_metrics[4];
+  double rel_improvement, immediate_weight;                   // learning.rs:37-55
+  double p_best_score, p_threshold, p_adaptive_lr, p_stagnation;   // contrast step, learning.rs:131-180
+  uint32_t stall, iteration_count;
+  int32_t has_best, has_cw, noop_boost, has_lists, p_forced;
+  uint32_t heur_min, heur_max;                                // sampling.rs:425-427
+  uint32_t n_improvements;     // improvements installed by on-device updates since the last upload (log entries written)
+  int32_t improved_last;       // the last on-device update installed a new best strategy
+  uint32_t pad;
+};
+static_assert(sizeof(DevState) % 8 == 0, "state layout");
+struct DevImprovement { double score, metrics[4]; uint32_t iteration, pad; };   // on-device improvement log entry
+
 // Policy snapshot in HBM: one packed buffer (filled by one copy from pinned memory), fixed layout.
 namespace snap {
 constexpr size_t kBestCap = 4096;     // best_actions can hold every replay-doubled year list
@@ -132,11 +149,20 @@ constexpr size_t best_off = bestd_mask + 8 * EG_YEARS;                      // i
 constexpr size_t bestd_off = best_off + 4 * 28;
 constexpr size_t best_actions = bestd_off + 4 * 28;                         // u8 [kBestCap]
 constexpr size_t bestd_actions = best_actions + kBestCap;
-constexpr size_t total = bestd_actions + kBestCap;
+constexpr size_t state = (bestd_actions + kBestCap + 15) & ~size_t(15);     // DevState
+constexpr size_t upload_bytes = state + sizeof(DevState);                   // what eg_upload_snapshot copies
+// device-resident policy only (on-device updates, eg_policy_pull):
+constexpr int kImpLogCap = 256;
+constexpr size_t best_w = (upload_bytes + 15) & ~size_t(15);                // f64 [26][61] main weights at the last improvement
+constexpr size_t imp_log = best_w + 8 * EG_YEARS * EG_N_ACTIONS;            // DevImprovement [kImpLogCap] (ring)
+constexpr size_t total = imp_log + sizeof(DevImprovement) * kImpLogCap;
 }  // namespace snap
 
 struct DevSnapshot {
   const uint8_t* base;
+  int32_t enable_energy_sales;   // run options (host)
+  int32_t write_yearly;
+  // the fields below are filled IN the kernel from snap::state (load_state); the host leaves them alone
   double learning_rate, exploration_rate;
   uint32_t stall;
   int32_t has_best;
@@ -145,13 +171,12 @@ struct DevSnapshot {
   double rel_improvement;      // learning.rs:37-49 evaluated on the host
   double immediate_weight;     // learning.rs:54
   int32_t has_best_actions, has_best_deficit;
-  uint32_t heur_min, heur_max;   // sampling.rs:425-427 evaluated on the host (count table absent)
-  int32_t enable_energy_sales;
-  int32_t write_yearly;
+  uint32_t heur_min, heur_max;   // sampling.rs:425-427 (count table absent)
 #define EG_SNAP(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + snap::name); }
   EG_SNAP(pol, double) EG_SNAP(scaled, double) EG_SNAP(scaled_perm, uint8_t)
   EG_SNAP(best_mask, unsigned long long) EG_SNAP(bestd_mask, unsigned long long)
   EG_SNAP(best_off, int32_t) EG_SNAP(bestd_off, int32_t) EG_SNAP(best_actions, uint8_t) EG_SNAP(bestd_actions, uint8_t)
+  EG_SNAP(state, DevState)
 #undef EG_SNAP
 };
 
@@ -195,12 +220,14 @@ void set_error(const std::string& s);
 struct StatsParams;
 struct UpdateCandidate;
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream,
+                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
                    bool helper_waves);
-int launch_stalled_tables(uint8_t* d_snap, double power, void* stream);
+int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
+int launch_apply_update(uint8_t* d_snap, long long* d_stats, const void* d_cands, int n_cands, uint64_t noise_seed, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
-// scalars of the contrast step that depend only on the snapshot (learning.rs:131-180), evaluated on the host
+// scalars of the contrast step that depend only on the snapshot (learning.rs:131-180); filled in the kernels from
+// snap::state
 struct StatsParams {
   double best_score;     // score_metrics(best_metrics)
   int32_t has_best;      // best metrics and best action lists present
@@ -209,7 +236,7 @@ struct StatsParams {
   double adaptive_lr;    // learning.rs:174
   double stagnation;     // learning.rs:163-164
 };
-int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream);
+int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream);
 // best episode of a batch, laid out right behind the statistics in the update packet (eg_rollout_launch_update)
 struct UpdateCandidate {
   double score;            // -1 when the batch has no successful episode

@@ -12,6 +12,9 @@
 
 #include "eg_internal.h"
 #include "eg_policy_internal.h"
+#define EG_RM static inline
+#include "eg_reduced_math.h"
+namespace rm = eg::rm;
 
 namespace {
 
@@ -44,21 +47,33 @@ struct HostRng {
       key[i] = (x >> rot) | (x << ((32 - rot) & 31));
     }
   }
-  void block(uint64_t ctr, uint32_t* out) const {
-    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u}, x[16];
-    for (int i = 0; i < 8; ++i) s[4 + i] = key[i];
-    s[12] = uint32_t(ctr); s[13] = uint32_t(ctr >> 32); s[14] = 0; s[15] = 0;
+  // rand_chacha refills four consecutive blocks at a time; they are computed side by side (x[word][block]) so that
+  // the compiler turns every step into one 4 x u32 vector operation
+  void refill() {
+    uint32_t s[16][4], x[16][4];
+    const uint32_t kc[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int l = 0; l < 4; ++l) {
+      for (int i = 0; i < 4; ++i) s[i][l] = kc[i];
+      for (int i = 0; i < 8; ++i) s[4 + i][l] = key[i];
+      const uint64_t ctr = counter + uint64_t(l);
+      s[12][l] = uint32_t(ctr); s[13][l] = uint32_t(ctr >> 32); s[14][l] = 0; s[15][l] = 0;
+    }
     std::memcpy(x, s, sizeof(x));
-    auto qr = [&](int a, int b, int c, int d) {
-      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
-      x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
-    };
-    for (int r = 0; r < 6; ++r) { qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
-                                  qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14); }
-    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+#define EG_QR4(a, b, c, d)                                                                                  \
+    for (int l = 0; l < 4; ++l) { x[a][l] += x[b][l]; x[d][l] = rotl(x[d][l] ^ x[a][l], 16); }                \
+    for (int l = 0; l < 4; ++l) { x[c][l] += x[d][l]; x[b][l] = rotl(x[b][l] ^ x[c][l], 12); }                \
+    for (int l = 0; l < 4; ++l) { x[a][l] += x[b][l]; x[d][l] = rotl(x[d][l] ^ x[a][l], 8); }                 \
+    for (int l = 0; l < 4; ++l) { x[c][l] += x[d][l]; x[b][l] = rotl(x[b][l] ^ x[c][l], 7); }
+    for (int r = 0; r < 6; ++r) {
+      EG_QR4(0, 4, 8, 12) EG_QR4(1, 5, 9, 13) EG_QR4(2, 6, 10, 14) EG_QR4(3, 7, 11, 15)
+      EG_QR4(0, 5, 10, 15) EG_QR4(1, 6, 11, 12) EG_QR4(2, 7, 8, 13) EG_QR4(3, 4, 9, 14)
+    }
+#undef EG_QR4
+    for (int l = 0; l < 4; ++l) for (int i = 0; i < 16; ++i) buf[16 * l + i] = x[i][l] + s[i][l];
+    counter += 4; index = 0;
   }
   uint64_t next_u64() {
-    if (index >= 63) { for (int b = 0; b < 4; ++b) block(counter + b, buf + 16 * b); counter += 4; index = 0; }
+    if (index >= 63) refill();
     uint64_t v = (uint64_t(buf[index + 1]) << 32) | buf[index]; index += 2; return v;
   }
   double next_f64() { return double(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
@@ -145,6 +160,7 @@ double eg_policy_get_scalar(const eg_policy* p, int32_t which) {
     case 5: case 6: case 7: case 8: return p->best_metrics[which - 5];
     case 9: return p->has_best_actions ? 1.0 : 0.0; case 10: return p->has_best_deficit ? 1.0 : 0.0;
     case 11: return p->has_cw ? 1.0 : 0.0;
+    case 12: return double(p->improvement_history.size());
     default: return 0.0;
   }
 }
@@ -261,37 +277,35 @@ int32_t eg_policy_apply_episode(eg_policy* p, const double metrics[4], const int
 int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double cand_metrics[4], const int32_t* cand_n_run,
                                 const uint8_t* cand_run_log, const int32_t* cand_n_def, const uint8_t* cand_def_log,
                                 uint64_t noise_seed) {
+  // Every formula comes from eg_reduced_math.h, which the device-side form of this update (k_apply_update) shares: the
+  // two produce identical policies from identical packets.
   if (!p || !stats) return EG_ERR_BAD_ARG;
   HostRng noise(noise_seed);
   const int64_t n_ok = stats[0], n_qual = stats[2];
   const int64_t* pen = stats + 8; const int64_t* mild = stats + 8 + Y * NA; const int64_t* dcnt = stats + 8 + 2 * Y * NA;
-  auto clampw = [](double v) { return v < kMinW ? kMinW : (v > kMaxW ? kMaxW : v); };
-  auto randomize = [&](double* row, int n) {
-    for (int i = 0; i < n; ++i) row[i] = clampw(row[i] * (1.0 + 0.25 * (noise.next_f64() * 2.0 - 1.0)));
-  };
-  if (p->has_best && p->has_best_actions && n_qual > 0) {   // apply_contrast_learning
-    const double k = double(p->stall);
-    const double stagnation_factor = 1.0 + (0.2 * std::pow(k / 10.0, 1.8));
-    const double adaptive_lr = p->learning_rate * (1.0 + 0.1 * k);
-    const double ln_boost = std::log(1.0 + (adaptive_lr * 2.0 * stagnation_factor));
+  // the rollout kernels see the best lists only when both are present (eg_policy_snapshot_view); so does this update
+  const bool have_lists = p->has_best && p->has_best_actions && p->has_best_deficit;
+  if (have_lists && n_qual > 0) {   // apply_contrast_learning
+    const double ln_boost = rm::contrast_ln_boost(p->learning_rate, p->stall);
     for (int y = 0; y < Y; ++y) {
       int occ[NA] = {0};
       for (uint8_t a : p->best_actions[y]) occ[a] += 1;
-      if (p->has_best_deficit) for (uint8_t a : p->best_deficit[y]) occ[a] += 1;
+      for (uint8_t a : p->best_deficit[y]) occ[a] += 1;
+      double* row = p->w[y].data();
       for (int a = 0; a < NA; ++a) {
         const double L = double(n_qual) * double(occ[a]) * ln_boost + (double(pen[y * NA + a]) + double(mild[y * NA + a])) / 4294967296.0;
-        if (L != 0.0) p->w[y][a] = clampw(p->w[y][a] * std::exp(L));
+        row[a] = rm::nudge(row[a], L);
       }
     }
-    if (p->stall > 1200) for (int y = 0; y < Y; ++y) randomize(p->w[y].data(), NA);
+    if (p->stall > 1200) for (int y = 0; y < Y; ++y) for (int a = 0; a < NA; ++a) p->w[y][a] = rm::noise(p->w[y][a], noise.next_f64());
   }
   // update_best_strategy with the batch's candidate
   p->iteration_count += uint32_t(n_ok);
   bool improved = false;
   if (cand_metrics && cand_n_run && cand_n_def && n_ok > 0)
-    improved = !p->has_best || eg_score_metrics(cand_metrics, 0) > eg_score_metrics(p->best_metrics.data(), 0);
+    improved = !p->has_best || rm::score(cand_metrics) > rm::score(p->best_metrics.data());
   if (improved) {
-    p->record_improvement(eg_score_metrics(cand_metrics, 0), cand_metrics);
+    p->record_improvement(rm::score(cand_metrics), cand_metrics);
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = cand_metrics[i];
     p->has_best_weights = true; p->best_w = p->w;
     for (int y = 0, rp = 0, dp = 0; y < Y; ++y) {
@@ -302,25 +316,19 @@ int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double
     p->has_best_actions = true; p->has_best_deficit = true; p->stall = 0;
   } else p->stall += uint32_t(n_ok);
   // apply_deficit_contrast_learning: the same factor for every episode (it depends on the stall counter only)
-  if (!improved && p->has_best && p->has_best_deficit) {
-    const double st = double(p->stall);
-    const double deterioration = st / 10.0;
-    const double threshold = 0.05 * std::fmax(std::exp(-st / 400.0), 0.00001 / 0.05);
-    if (deterioration > threshold || p->stall > 800) {
-      const double stagnation_factor = 1.0 + (0.2 * std::pow(st / 10.0, 1.8));
-      const double combined_penalty = std::pow(deterioration, 0.3) * stagnation_factor;
-      const double adaptive_lr = p->learning_rate * (1.0 + 0.1 * st);
-      const double ln_pen = std::log(1.0 / (1.0 + adaptive_lr * 1.5 * combined_penalty));
-      const double ln_boost = std::log(1.0 + (adaptive_lr * 2.0 * stagnation_factor * 1.5));
+  if (!improved && have_lists) {
+    const rm::DeficitContrast dc = rm::deficit_contrast(p->learning_rate, p->stall);
+    if (dc.active) {
       for (int y = 0; y < Y; ++y) {
         int occ[ND] = {0};
         for (uint8_t a : p->best_deficit[y]) { const int s = deficit_slot(a); if (s >= 0) occ[s] += 1; }
+        double* row = p->dw[y].data();
         for (int s = 0; s < ND; ++s) {
-          const double L = double(n_ok) * double(occ[s]) * ln_boost + double(dcnt[y * ND + s]) * ln_pen;
-          if (L != 0.0) p->dw[y][s] = clampw(p->dw[y][s] * std::exp(L));
+          const double L = double(n_ok) * double(occ[s]) * dc.ln_boost + double(dcnt[y * ND + s]) * dc.ln_pen;
+          row[s] = rm::nudge(row[s], L);
         }
       }
-      if (p->stall > 1200) for (int y = 0; y < Y; ++y) randomize(p->dw[y].data(), ND);
+      if (p->stall > 1200) for (int y = 0; y < Y; ++y) for (int s = 0; s < ND; ++s) p->dw[y][s] = rm::noise(p->dw[y][s], noise.next_f64());
     }
   }
   return improved ? 1 : EG_OK;

@@ -22,6 +22,8 @@
 
 #define EG_DETPOW_QUAL __device__ __forceinline__
 #include "eg_detpow.h"
+#define EG_RM __device__ __forceinline__
+#include "eg_reduced_math.h"
 
 namespace eg {
 namespace {
@@ -607,12 +609,15 @@ struct Episode {   // wave-uniform bookkeeping of one episode
 constexpr int kStatsMain = EG_YEARS * EG_N_ACTIONS;
 constexpr double kQ32 = 4294967296.0;
 
-__device__ double device_score(const double* m) {   // ai/metrics/scoring.rs:18-44 (mode None)
-  if (m[0] > 0.0) return 1.0 - dmin(m[0] / 1000000.0, 1.0);
-  const double normalized_cost = dmax(m[2] / kMaxCost, 1.0);
-  const double cost_score = 1.0 - dmin(log(normalized_cost) / log(kMaxCost * 100.0 / kMaxCost), 1.0);
-  const double cost_weight = normalized_cost > 8.0 ? 0.8 : 0.5;
-  return 1.0 + (cost_score * cost_weight + m[1] * (1.0 - cost_weight));
+// The policy's scalars as the kernels use them: always read from the snapshot buffer (snap::state), where the host
+// upload or the last on-device update left them.
+__device__ __forceinline__ void load_state(DevSnapshot& S, StatsParams& P) {
+  const DevState& st = *S.state();
+  S.learning_rate = st.learning_rate; S.exploration_rate = st.exploration_rate; S.stall = st.stall; S.has_best = st.has_best;
+  S.has_cw = st.has_cw; S.noop_boost = st.noop_boost; S.rel_improvement = st.rel_improvement; S.immediate_weight = st.immediate_weight;
+  S.has_best_actions = st.has_lists; S.has_best_deficit = st.has_lists; S.heur_min = st.heur_min; S.heur_max = st.heur_max;
+  P.best_score = st.p_best_score; P.has_best = st.has_lists; P.threshold = st.p_threshold; P.forced = st.p_forced;
+  P.adaptive_lr = st.p_adaptive_lr; P.stagnation = st.p_stagnation;
 }
 
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
@@ -622,7 +627,7 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
     if (lane == 0) { atomicAdd(&st[1], 1ull); *O.score(e) = -1.0; }
     return;
   }
-  const double score = device_score(O.metrics(e));
+  const double score = rm::score(O.metrics(e));
   if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
@@ -676,9 +681,10 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 #endif
 
 template <int kHelpers>
-__global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables T, DevSnapshot S, DevOut O, unsigned long long seed,
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
-                                                                    const uint8_t* __restrict__ replay_mask, StatsParams P, long long* stats) {
+                                                                    const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
+                                                                    long long* stats) {
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
@@ -687,7 +693,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave > 0) { helper_loop(T, lane, wave); return; }
   }
-  const bool replay = replay_mask != nullptr && replay_mask[e] != 0;   // iteration.rs:34-42
+  DevSnapshot S = S_in; StatsParams P;
+  load_state(S, P);
+  // iteration.rs:34-42: which episodes replay the best strategy comes from the caller's mask or, when the policy lives on
+  // the device (the host cannot know whether a best strategy exists yet), from a period over the global episode index
+  const bool replay = replay_mask != nullptr ? replay_mask[e] != 0
+                                             : (replay_period != 0u && S.has_best_actions && (first_index + e) % replay_period == 0ull);
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
   unsigned long long stamps[32] = {};
@@ -1079,9 +1090,13 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
 // Stalled sampler tables of a freshly uploaded snapshot (sampling.rs:190-220 on the un-nudged rows): per year the
 // weights in stable descending order raised to the power (shared eg_detpow), the permutation and the table-order sum.
 // One workgroup per year; runs on the stream right behind the snapshot copy.
-__global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base, double power) {
+__global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base) {
   __shared__ double s_w[64], s_scaled[64];
   const int y = blockIdx.x, lane = threadIdx.x;
+  const uint32_t stall = reinterpret_cast<const DevState*>(snap_base + snap::state)->stall;
+  if (stall <= 500u) return;
+  const double stagnation = rm::dmind((double)stall / 1000.0, 3.0);
+  const double power = 1.0 + (2.0 * stagnation);
   double* row = reinterpret_cast<double*>(snap_base + snap::pol) + y * snap::kPolRow;
   const double* w = row;
   double* scaled = reinterpret_cast<double*>(snap_base + snap::scaled) + y * 64;
@@ -1104,9 +1119,11 @@ __global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base, do
 }
 
 // statistics of a finished batch without re-running it (same accumulation as the k_rollout epilogue)
-__global__ void __launch_bounds__(kWave) k_update_stats(DevOut O, DevSnapshot S, StatsParams P, uint32_t n, long long* stats) {
+__global__ void __launch_bounds__(kWave) k_update_stats(DevOut O, DevSnapshot S_in, uint32_t n, long long* stats) {
   const uint32_t e = blockIdx.x;
   if (e >= n) return;
+  DevSnapshot S = S_in; StatsParams P;
+  load_state(S, P);
   episode_update_stats(O, S, P, e, threadIdx.x, stats);
 }
 
@@ -1139,18 +1156,182 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
   for (int i = tid; i < EG_DEF_CAP; i += 1024) cand->def_log[i] = O.def_log(win)[i];
 }
 
+// ---- on-device batch update (eg_policy_apply_reduced, eg_policy.cpp, restated for one 1024-thread workgroup) -----------
+// The policy lives in the snapshot buffer; this kernel consumes the (all-reduced) statistics and the candidate records
+// of a batch and leaves the buffer as eg_upload_snapshot would have written it after the host update: weights, row
+// sums, best lists / offsets / masks, scalars (derive_state) — the same bits, because every formula comes from
+// eg_reduced_math.h.  The stalled sampler tables follow in k_stalled_tables.  The statistics are zeroed for the next batch.
+__device__ void chacha12_block(const uint32_t* key, unsigned long long counter, uint32_t* out) {
+  uint32_t s[16], x[16];
+  s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[4 + i] = key[i];
+  s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0u; s[15] = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
+    EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+}
+
+__global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long long* stats, const uint8_t* cands, int n_cands,
+                                                      unsigned long long noise_seed) {
+  constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
+  constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
+  __shared__ uint32_t s_noise[kBlocks * 16];
+  __shared__ uint32_t s_key[8];
+  __shared__ DevState st;
+  __shared__ int s_winner, s_improved, s_randomized_main;
+  __shared__ int s_prefix[2][Y + 1];
+  const int tid = threadIdx.x;
+  double* pol = reinterpret_cast<double*>(snap_base + snap::pol);
+  int32_t* best_off = reinterpret_cast<int32_t*>(snap_base + snap::best_off);
+  int32_t* bestd_off = reinterpret_cast<int32_t*>(snap_base + snap::bestd_off);
+  uint8_t* best_actions = snap_base + snap::best_actions;
+  uint8_t* bestd_actions = snap_base + snap::bestd_actions;
+  DevState* gstate = reinterpret_cast<DevState*>(snap_base + snap::state);
+
+  if (tid == 0) {
+    st = *gstate;
+    // the batch's candidate: highest score, ties to the lowest global index (eg_policy_apply_packet)
+    int win = -1; double ws = 0.0; long long wi = 0;
+    for (int r = 0; r < n_cands; ++r) {
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)r * EG_CANDIDATE_BYTES);
+      if (c->index < 0) continue;
+      if (win < 0 || c->score > ws || (c->score == ws && c->index < wi)) { win = r; ws = c->score; wi = c->index; }
+    }
+    s_winner = win;
+    unsigned long long state = noise_seed;      // rand_core seed_from_u64 (HostRng)
+    for (int i = 0; i < 8; ++i) {
+      state = state * 6364136223846793005ull + 11634580027462260723ull;
+      const uint32_t x = (uint32_t)(((state >> 18) ^ state) >> 27), rot = (uint32_t)(state >> 59);
+      s_key[i] = (x >> rot) | (x << ((32u - rot) & 31u));
+    }
+  }
+  __syncthreads();
+  const long long n_ok = stats[0], n_qual = stats[2];
+  const long long* pen = stats + 8; const long long* mild = stats + 8 + Y * NA; const long long* dcnt = stats + 8 + 2 * Y * NA;
+  const bool contrast = st.has_best && st.has_lists && n_qual > 0;
+  const bool randomize_main = contrast && st.stall > 1200u;
+  // the noise stream is only needed beyond 1200 stalled episodes; the deficit table may need it even if the main one
+  // did not (its stall counter is the updated one), so the blocks are made whenever either could
+  const bool maybe_noise = st.stall + (uint32_t)n_ok > 1200u;
+  if (maybe_noise && tid < kBlocks) chacha12_block(s_key, (unsigned long long)tid, s_noise + 16 * tid);
+  __syncthreads();
+  auto draw = [&](int j) {      // j-th gen::<f64>() of the stream
+    const unsigned long long v = ((unsigned long long)s_noise[2 * j + 1] << 32) | s_noise[2 * j];
+    return (double)(v >> 11) * (1.0 / 9007199254740992.0);
+  };
+
+  // ---- apply_contrast_learning over the batch ----
+  if (contrast) {
+    const double ln_boost = rm::contrast_ln_boost(st.learning_rate, st.stall);
+    for (int i = tid; i < Y * NA; i += 1024) {
+      const int y = i / NA, a = i - y * NA;
+      int occ = 0;
+      for (int k = best_off[y]; k < best_off[y + 1]; ++k) occ += best_actions[k] == a ? 1 : 0;
+      for (int k = bestd_off[y]; k < bestd_off[y + 1]; ++k) occ += bestd_actions[k] == a ? 1 : 0;
+      const double L = (double)n_qual * (double)occ * ln_boost + ((double)pen[i] + (double)mild[i]) / 4294967296.0;
+      double w = rm::nudge(pol[y * snap::kPolRow + a], L);
+      if (randomize_main) w = rm::noise(w, draw(i));
+      pol[y * snap::kPolRow + a] = w;
+    }
+  }
+  __syncthreads();
+
+  // ---- update_best_strategy with the batch's candidate ----
+  if (tid == 0) {
+    bool improved = false;
+    if (s_winner >= 0 && n_ok > 0) {
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
+      improved = !st.has_best || rm::score(c->metrics) > rm::score(st.best_metrics);
+    }
+    st.iteration_count += (uint32_t)n_ok;
+    s_improved = improved ? 1 : 0;
+    s_randomized_main = randomize_main ? 1 : 0;
+    if (improved) {
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
+      DevImprovement* log = reinterpret_cast<DevImprovement*>(snap_base + snap::imp_log) + (st.n_improvements % snap::kImpLogCap);
+      log->score = rm::score(c->metrics); log->iteration = st.iteration_count; log->pad = 0;
+      for (int k = 0; k < 4; ++k) { log->metrics[k] = c->metrics[k]; st.best_metrics[k] = c->metrics[k]; }
+      st.n_improvements += 1;
+      st.has_best = 1; st.has_lists = 1; st.stall = 0;
+      int a = 0, b = 0;
+      for (int y = 0; y < Y; ++y) { s_prefix[0][y] = a; s_prefix[1][y] = b; a += c->n_run[y]; b += c->n_def[y]; }
+      s_prefix[0][Y] = a; s_prefix[1][Y] = b;
+    } else st.stall += (uint32_t)n_ok;
+    st.improved_last = improved ? 1 : 0;
+  }
+  __syncthreads();
+  const bool improved = s_improved != 0;
+  if (improved) {      // the candidate's lists become the best lists; the main weights of this moment are kept beside them
+    const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
+    const int nr = s_prefix[0][Y], nd = s_prefix[1][Y];
+    for (int i = tid; i < nr && i < (int)snap::kBestCap; i += 1024) best_actions[i] = c->run_log[i];
+    for (int i = tid; i < nd && i < (int)snap::kBestCap; i += 1024) bestd_actions[i] = c->def_log[i];
+    if (tid <= Y) { best_off[tid] = s_prefix[0][tid]; bestd_off[tid] = s_prefix[1][tid]; }
+    if (tid < Y) {
+      unsigned long long m = 0, dm = 0;
+      for (int k = s_prefix[0][tid]; k < s_prefix[0][tid + 1]; ++k) if (c->run_log[k] < 64) m |= 1ull << c->run_log[k];
+      for (int k = s_prefix[1][tid]; k < s_prefix[1][tid + 1]; ++k) if (c->def_log[k] < 64) { m |= 1ull << c->def_log[k]; dm |= 1ull << c->def_log[k]; }
+      reinterpret_cast<unsigned long long*>(snap_base + snap::best_mask)[tid] = m;
+      reinterpret_cast<unsigned long long*>(snap_base + snap::bestd_mask)[tid] = dm;
+    }
+    double* best_w = reinterpret_cast<double*>(snap_base + snap::best_w);
+    for (int i = tid; i < Y * NA; i += 1024) { const int y = i / NA, a = i - y * NA; best_w[i] = pol[y * snap::kPolRow + a]; }
+  }
+
+  // ---- apply_deficit_contrast_learning: the same factor for every episode (it depends on the stall counter only) ----
+  if (!improved && st.has_best && st.has_lists) {
+    const rm::DeficitContrast dc = rm::deficit_contrast(st.learning_rate, st.stall);
+    if (dc.active) {
+      const bool randomize = st.stall > 1200u;
+      const int first_draw = s_randomized_main ? kMainDraws : 0;
+      for (int i = tid; i < Y * ND; i += 1024) {
+        const int y = i / ND, sl = i - y * ND;
+        int occ = 0;
+        for (int k = bestd_off[y]; k < bestd_off[y + 1]; ++k) {
+          const int a = bestd_actions[k];
+          const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
+          occ += slot == sl ? 1 : 0;
+        }
+        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)dcnt[i] * dc.ln_pen;
+        double w = rm::nudge(pol[y * snap::kPolRow + snap::kPolDw + sl], L);
+        if (randomize) w = rm::noise(w, draw(first_draw + i));
+        pol[y * snap::kPolRow + snap::kPolDw + sl] = w;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- what eg_upload_snapshot derives: row sums in table order, scalars ----
+  if (tid < Y) {
+    double* row = pol + tid * snap::kPolRow;
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < NA; ++i) a += row[i];
+    for (int i = 0; i < 14; ++i) b += row[snap::kPolDw + i];
+    row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
+  }
+  if (tid == 0) { rm::derive_state(st); *gstate = st; }
+  for (int i = tid; i < EG_STATS_LEN; i += 1024) stats[i] = 0;      // ready for the next batch's epilogue
+}
+
 }  // namespace
 
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, const StatsParams& p, long long* d_stats, void* stream,
+                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
                    bool helper_waves) {
   if (n == 0) return 0;
   if (helper_waves)
     hipLaunchKernelGGL(k_rollout<kHelperWaves>, dim3(n), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream, t, s, o,
-                       (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
+                       (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
   else
     hipLaunchKernelGGL(k_rollout<0>, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
-                       (unsigned long long)first_index, n, d_replay_mask, p, d_stats);
+                       (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
@@ -1159,13 +1340,18 @@ int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_
                      d_out_cell, d_out_score);
   return (int)hipGetLastError();
 }
-int launch_stalled_tables(uint8_t* d_snap, double power, void* stream) {
-  hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap, power);
+int launch_stalled_tables(uint8_t* d_snap, void* stream) {
+  hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap);
   return (int)hipGetLastError();
 }
-int launch_update_stats(const DevSnapshot& s, const DevOut& o, const StatsParams& p, uint32_t n, long long* d_stats, void* stream) {
+int launch_apply_update(uint8_t* d_snap, long long* d_stats, const void* d_cands, int n_cands, uint64_t noise_seed, void* stream) {
+  hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, d_stats, (const uint8_t*)d_cands, n_cands,
+                     (unsigned long long)noise_seed);
+  return (int)hipGetLastError();
+}
+int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {
   if (n == 0) return 0;
-  hipLaunchKernelGGL(k_update_stats, dim3(n), dim3(kWave), 0, (hipStream_t)stream, o, s, p, n, d_stats);
+  hipLaunchKernelGGL(k_update_stats, dim3(n), dim3(kWave), 0, (hipStream_t)stream, o, s, n, d_stats);
   return (int)hipGetLastError();
 }
 int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCandidate* d_cand, void* stream) {

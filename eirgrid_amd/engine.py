@@ -71,7 +71,7 @@ class ActionWeights:
     """ActionWeights held by the library (eg_policy): tables, best strategy, counters."""
     SC = dict(learning_rate=0, exploration_rate=1, iterations_without_improvement=2, iteration_count=3, has_best=4,
               best_net_emissions=5, best_opinion=6, best_cost=7, best_reliability=8, has_best_actions=9,
-              has_best_deficit_actions=10, has_count_weights=11)
+              has_best_deficit_actions=10, has_count_weights=11, improvement_history_len=12)
 
     def __init__(self, handle=None):
         self.h = handle if handle is not None else N.lib().eg_policy_new()
@@ -294,6 +294,26 @@ class Engine:
         if rc < 0:
             N.check(rc, "eg_train_step")
         return rc == 1
+
+    # ---- device-resident policy (include/eirgrid_hip.h: eg_policy_push ... eg_policy_pull) ----
+    def push(self, weights: ActionWeights, enable_energy_sales=True, write_yearly=True):
+        opts = self._opts(enable_energy_sales, False, write_yearly)
+        N.check(N.lib().eg_policy_push(self.h, weights.h, C.byref(opts)), "eg_policy_push")
+
+    def device_rollout(self, seed: int, first_episode_index: int, n_episodes: int, replay_period: int, d_packet_ptr: int):
+        N.check(N.lib().eg_device_rollout(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index), n_episodes,
+                                          replay_period, C.c_void_p(d_packet_ptr)), "eg_device_rollout")
+
+    def device_apply(self, d_stats_ptr: int, d_candidates_ptr: int, n_candidates: int, noise_seed: int):
+        N.check(N.lib().eg_device_apply(self.h, C.c_void_p(d_stats_ptr), C.c_void_p(d_candidates_ptr), n_candidates,
+                                        C.c_uint64(noise_seed & (2**64 - 1))), "eg_device_apply")
+
+    def device_step(self, seed: int, first_episode_index: int, n_episodes: int, replay_period: int, noise_seed: int):
+        N.check(N.lib().eg_device_step(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index), n_episodes,
+                                       replay_period, C.c_uint64(noise_seed & (2**64 - 1))), "eg_device_step")
+
+    def pull(self, weights: ActionWeights):
+        N.check(N.lib().eg_policy_pull(self.h, weights.h), "eg_policy_pull")
 
     def sync(self):
         N.check(N.lib().eg_sync(self.h), "eg_sync")

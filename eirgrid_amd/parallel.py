@@ -126,10 +126,17 @@ def exchange_update(stats, local_pair, local_payload_fn, dist=None, device=None)
 
 
 class BatchTrainer:
-    """Rollout + batch update loop of one rank (the driver of configs 2-4)."""
+    """Rollout + batch update loop of one rank (the driver of configs 2-4).
+
+    device_resident (default on one GPU and under RCCL): the policy is pushed to the device once and every step is
+    enqueued without a host synchronisation — rollout with the statistics epilogue, best pick, (all-reduce + all-gather,)
+    k_apply_update, stalled tables; `weights` is refreshed by sync().  Otherwise (gloo rehearsals on the CPU side of
+    the exchange) each step uploads the snapshot, copies the packet to the host and updates `weights` there.  Both
+    leave the same policy behind, bit for bit (tests/test_gpu_update.py)."""
 
     def __init__(self, engine: Engine, weights: ActionWeights, episodes_per_rank: int, seed: int, rank: int = 0,
-                 world_size: int = 1, dist=None, replay_fraction: float = 0.0, write_yearly: bool = True):
+                 world_size: int = 1, dist=None, replay_fraction: float = 0.0, write_yearly: bool = True,
+                 device_resident=None):
         import torch
         self.torch, self.dist = torch, dist
         self.eng, self.w = engine, weights
@@ -137,19 +144,55 @@ class BatchTrainer:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.packet = torch.zeros(N.PACKET_BYTES, dtype=torch.uint8, device=self.device)
         self.replay_fraction = replay_fraction
+        self.replay_period = max(1, int(round(1.0 / replay_fraction))) if replay_fraction > 0.0 else 0
         self.write_yearly = write_yearly
         self.step_index = 0
-        self.improvements = 0
+        multi = dist is not None and world_size > 1
+        if device_resident is None:
+            device_resident = (not multi) or dist.get_backend() == "nccl"
+        self.device_resident = bool(device_resident)
+        self._history0 = int(weights.get("improvement_history_len"))
+        self._improvements_host = 0
+        if self.device_resident:
+            if multi:
+                self.gathered = torch.zeros(world_size * N.CANDIDATE_BYTES, dtype=torch.uint8, device=self.device)
+            self.eng.push(weights, write_yearly=write_yearly)
 
-    def step(self) -> bool:
-        """One pass of the hot path: rollout of this rank's shard, update statistics, the exchange, the update."""
+    @property
+    def improvements(self) -> int:
+        """New best strategies since construction (device-resident mode: as of the last sync())."""
+        if self.device_resident:
+            return int(self.w.get("improvement_history_len")) - self._history0
+        return self._improvements_host
+
+    def sync(self):
+        """Wait for the enqueued steps and bring `weights` up to date (device-resident mode)."""
+        if self.device_resident:
+            self.eng.pull(self.w)
+        else:
+            self.eng.sync()
+
+    def step(self):
+        """One pass of the hot path: rollout of this rank's shard, update statistics, the exchange, the update.
+        Returns whether a new best strategy was installed (None in device-resident mode: nothing is read back)."""
         total = self.n * self.ws
         first = self.step_index * total + self.rank * self.n           # global episode index of this shard
-        mask = None
-        if self.replay_fraction > 0.0 and self.w.get("has_best_actions") == 1:
-            period = max(1, int(round(1.0 / self.replay_fraction)))
-            mask = ((np.arange(first, first + self.n) % period) == 0).astype(np.uint8)
         noise = self.seed + self.step_index
+        nstat = 8 * N.STATS_LEN
+        if self.device_resident:
+            if self.dist is None or self.ws == 1:
+                self.eng.device_step(self.seed, first, self.n, self.replay_period, noise)
+            else:
+                self.eng.device_rollout(self.seed, first, self.n, self.replay_period, self.packet.data_ptr())
+                stats = self.packet[:nstat].view(self.torch.int64)
+                self.dist.all_reduce(stats, op=self.dist.ReduceOp.SUM)      # the one all-reduce of the update (RCCL over xGMI)
+                self.dist.all_gather_into_tensor(self.gathered, self.packet[nstat:])
+                self.eng.device_apply(self.packet.data_ptr(), self.gathered.data_ptr(), self.ws, noise)
+            self.step_index += 1
+            return None
+        mask = None
+        if self.replay_period > 0 and self.w.get("has_best_actions") == 1:
+            mask = ((np.arange(first, first + self.n) % self.replay_period) == 0).astype(np.uint8)
         if self.dist is None or self.ws == 1:      # one GPU: the whole step is one library call
             improved = self.eng.train_step(self.w, self.seed, first, self.n, mask, noise_seed=noise, write_yearly=self.write_yearly)
         else:
@@ -157,6 +200,6 @@ class BatchTrainer:
             self.eng.launch_update(self.seed, first, self.n, self.packet.data_ptr(), mask)   # rollout + stats + best pick
             stats, cands = exchange_packet_raw(self.packet, self.dist)                        # all-reduce + one D2H copy
             improved = apply_packet(self.w, stats, cands, noise_seed=noise)
-        self.improvements += int(improved)
+        self._improvements_host += int(improved)
         self.step_index += 1
         return improved

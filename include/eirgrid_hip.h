@@ -222,6 +222,22 @@ int32_t eg_policy_apply_packet(eg_policy *, const int64_t *stats, const void *ca
  * epilogue, best pick, ONE packet copy to pinned host memory, eg_policy_apply_packet.  Same return convention. */
 int32_t eg_train_step(eg_ctx *, eg_policy *, const eg_opts *opts, uint64_t seed, uint64_t first_episode_index,
                       uint32_t n_episodes, const uint8_t *replay_mask /* host, may be NULL */, uint64_t noise_seed);
+/* Device-resident policy.  eg_policy_push uploads the policy once; after that every training step runs on the device with
+ * no host synchronisation: eg_device_rollout enqueues the rollout (statistics epilogue, best pick) into `d_packet`
+ * (DEVICE, EG_PACKET_BYTES, zeroed once by the caller), eg_device_apply enqueues the batch update from the summed
+ * statistics and n_candidates candidate records (DEVICE pointers; between the two calls a multi-GPU caller all-reduces the
+ * statistics part and all-gathers the candidate records on the same stream) and zeroes the statistics for the next step.
+ * eg_device_step does both on a library-owned packet (one GPU).  The update is the one of eg_policy_apply_packet, bit for
+ * bit (both evaluate csrc/eg_reduced_math.h).  replay_period > 0: episode with global index i replays the best strategy
+ * when i % replay_period == 0 and a best strategy exists (decided on the device).  eg_policy_pull waits for the stream
+ * and copies the policy back into `policy` (tables, best strategy, counters, improvement history). */
+int32_t eg_policy_push(eg_ctx *, const eg_policy *, const eg_opts *opts);
+int32_t eg_device_rollout(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
+                          void *d_packet);
+int32_t eg_device_apply(eg_ctx *, void *d_stats, const void *d_candidates, int32_t n_candidates, uint64_t noise_seed);
+int32_t eg_device_step(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
+                       uint64_t noise_seed);
+int32_t eg_policy_pull(eg_ctx *, eg_policy *);
 /* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */

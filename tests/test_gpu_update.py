@@ -109,15 +109,19 @@ def test_reduced_update_moves_weights_the_right_way(engine):
 
 
 def test_trainer_steps_are_deterministic(engine):
+    """BatchTrainer in both modes (host updates / device-resident policy): repeatable, and the two modes agree."""
     runs = []
-    for _ in range(2):
+    for device_resident in (False, False, True, True):
         pol = ActionWeights()
-        tr = BatchTrainer(engine, pol, 128, 4321, replay_fraction=0.1)
+        tr = BatchTrainer(engine, pol, 128, 4321, replay_fraction=0.1, device_resident=device_resident)
         flags = [tr.step() for _ in range(6)]
+        tr.sync()
         w, dw, _ = pol.tables()
-        runs.append((flags, w.tobytes(), dw.tobytes(), pol.get("iteration_count"), pol.lists(0)))
-    assert runs[0] == runs[1]
-    assert runs[0][0][0] is True and runs[0][3] == 6 * 128
+        runs.append((w.tobytes(), dw.tobytes(), pol.get("iteration_count"), pol.lists(0), tr.improvements))
+        if not device_resident:
+            assert flags[0] is True and sum(flags) == tr.improvements
+    assert runs[0] == runs[1] == runs[2] == runs[3]
+    assert runs[0][2] == 6 * 128 and runs[0][4] >= 1
 
 
 def test_fused_packet_matches_separate_kernels(engine):
@@ -177,3 +181,42 @@ def test_train_step_equals_the_stepwise_path(engine):
         assert a.lists(0) == b.lists(0) and a.lists(1) == b.lists(1)
         for name in ("iterations_without_improvement", "iteration_count", "has_best", "best_cost", "best_net_emissions"):
             assert a.get(name) == b.get(name), name
+
+
+def test_device_resident_training_equals_host_updates(engine, world):
+    """eg_policy_push + eg_device_step (rollout, statistics, best pick, k_apply_update, stalled tables: all on the device,
+    no host copy) must leave the policy exactly where eg_train_step (host update from the same packets) leaves it —
+    weights, best strategy, counters — at every step, through the first improvement, the stalled sampler (> 500) and
+    the stagnation noise (> 1200)."""
+    from eirgrid_amd.engine import Engine
+    dev = Engine(world, device=0)
+    try:
+        a, b = ActionWeights(), ActionWeights()
+        n, period = 160, 4
+        dev.push(b)
+        improved_steps = 0; max_stall = 0
+        steps = 40
+        for step in range(steps):
+            first = step * n
+            mask = ((np.arange(first, first + n) % period) == 0).astype(np.uint8) if a.get("has_best_actions") == 1 else None
+            improved_steps += int(engine.train_step(a, 4711, first, n, mask, noise_seed=900 + step))
+            dev.device_step(4711, first, n, period, 900 + step)
+            dev.pull(b)
+            max_stall = max(max_stall, a.get("iterations_without_improvement"))
+            for x, y, name in zip(a.tables(), b.tables(), ("weights", "deficit weights", "count weights")):
+                assert x.tobytes() == y.tobytes(), f"step {step}: {name} differ"
+            assert a.lists(0) == b.lists(0) and a.lists(1) == b.lists(1), f"step {step}: best lists differ"
+            for name in ("iterations_without_improvement", "iteration_count", "has_best", "best_cost", "best_net_emissions",
+                         "best_opinion", "best_reliability", "has_best_actions", "has_best_deficit_actions"):
+                assert a.get(name) == b.get(name), f"step {step}: {name}"
+        assert improved_steps >= 1 and max_stall > 1200
+        # the same without any pull in between: the device loop is self-contained
+        c = ActionWeights(); dev.push(c)
+        for step in range(steps):
+            dev.device_step(4711, step * n, n, period, 900 + step)
+        dev.pull(c)
+        for x, y in zip(a.tables(), c.tables()):
+            assert x.tobytes() == y.tobytes()
+        assert a.lists(0) == c.lists(0) and a.get("iteration_count") == c.get("iteration_count")
+    finally:
+        dev.close()
