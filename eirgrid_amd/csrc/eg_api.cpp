@@ -318,10 +318,8 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   }
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
-  EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
   c->last_n = n;
   return EG_OK;
@@ -341,10 +339,8 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
-  EG_HIP(hipEventRecord(c->ev0, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
   c->last_n = n;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
@@ -436,11 +432,9 @@ int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   if (rc != EG_OK) return rc;
   rc = collect_timing(c);
   if (rc != EG_OK) return rc;
-  EG_HIP(hipEventRecord(c->ev0, nullptr));
   int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, nullptr, replay_period, (long long*)d_packet, nullptr,
-                          n <= c->helper_max_episodes);
+                          n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  EG_HIP(hipEventRecord(c->ev1, nullptr));
   c->timing_pending = true;
   c->last_n = n;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);

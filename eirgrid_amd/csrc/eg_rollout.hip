@@ -17,6 +17,7 @@
 //   metrics        analysis/metrics_calculation.rs:7-175, ai/metrics/scoring.rs:46-85
 //   RNG            rand 0.8.5 StdRng = ChaCha12 behind rand_core BlockRng (Cargo.lock:763-785)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "eg_internal.h"
 
@@ -1195,7 +1196,9 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
   uint8_t* bestd_actions = snap_base + snap::bestd_actions;
   DevState* gstate = reinterpret_cast<DevState*>(snap_base + snap::state);
 
-  if (tid == 0) {
+  // serial pieces run on different waves side by side: state + winner + "is it an improvement" on wave 1, the noise key on
+  // wave 0
+  if (tid == 64) {
     st = *gstate;
     // the batch's candidate: highest score, ties to the lowest global index (eg_policy_apply_packet)
     int win = -1; double ws = 0.0; long long wi = 0;
@@ -1205,6 +1208,14 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
       if (win < 0 || c->score > ws || (c->score == ws && c->index < wi)) { win = r; ws = c->score; wi = c->index; }
     }
     s_winner = win;
+    bool improved = false;
+    if (win >= 0 && stats[0] > 0) {
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)win * EG_CANDIDATE_BYTES);
+      improved = !st.has_best || rm::score(c->metrics) > rm::score(st.best_metrics);
+    }
+    s_improved = improved ? 1 : 0;
+  }
+  if (tid == 0) {
     unsigned long long state = noise_seed;      // rand_core seed_from_u64 (HostRng)
     for (int i = 0; i < 8; ++i) {
       state = state * 6364136223846793005ull + 11634580027462260723ull;
@@ -1245,13 +1256,8 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
 
   // ---- update_best_strategy with the batch's candidate ----
   if (tid == 0) {
-    bool improved = false;
-    if (s_winner >= 0 && n_ok > 0) {
-      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
-      improved = !st.has_best || rm::score(c->metrics) > rm::score(st.best_metrics);
-    }
+    const bool improved = s_improved != 0;
     st.iteration_count += (uint32_t)n_ok;
-    s_improved = improved ? 1 : 0;
     s_randomized_main = randomize_main ? 1 : 0;
     if (improved) {
       const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
@@ -1316,7 +1322,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
     for (int i = 0; i < 14; ++i) b += row[snap::kPolDw + i];
     row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
   }
-  if (tid == 0) { rm::derive_state(st); *gstate = st; }
+  if (tid == 64) { rm::derive_state(st); *gstate = st; }            // beside the row sums of wave 0
   for (int i = tid; i < EG_STATS_LEN; i += 1024) stats[i] = 0;      // ready for the next batch's epilogue
 }
 
@@ -1324,14 +1330,16 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
 
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
-                   bool helper_waves) {
+                   bool helper_waves, void* ev_start, void* ev_stop) {
   if (n == 0) return 0;
+  // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
   if (helper_waves)
-    hipLaunchKernelGGL(k_rollout<kHelperWaves>, dim3(n), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream, t, s, o,
-                       (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
+    hipExtLaunchKernelGGL(k_rollout<kHelperWaves>, dim3(n), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
+                          (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0, t, s, o, (unsigned long long)seed,
+                          (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
   else
-    hipLaunchKernelGGL(k_rollout<0>, dim3(n), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)seed,
-                       (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
+    hipExtLaunchKernelGGL(k_rollout<0>, dim3(n), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0,
+                          t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,

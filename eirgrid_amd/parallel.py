@@ -136,7 +136,7 @@ class BatchTrainer:
 
     def __init__(self, engine: Engine, weights: ActionWeights, episodes_per_rank: int, seed: int, rank: int = 0,
                  world_size: int = 1, dist=None, replay_fraction: float = 0.0, write_yearly: bool = True,
-                 device_resident=None):
+                 device_resident=None, force_collectives: bool = False):
         import torch
         self.torch, self.dist = torch, dist
         self.eng, self.w = engine, weights
@@ -147,7 +147,9 @@ class BatchTrainer:
         self.replay_period = max(1, int(round(1.0 / replay_fraction))) if replay_fraction > 0.0 else 0
         self.write_yearly = write_yearly
         self.step_index = 0
-        multi = dist is not None and world_size > 1
+        # force_collectives: run the all-reduce / all-gather even with one rank (exercises the RCCL path on one GPU)
+        multi = dist is not None and (world_size > 1 or force_collectives)
+        self.multi = multi
         if device_resident is None:
             device_resident = (not multi) or dist.get_backend() == "nccl"
         self.device_resident = bool(device_resident)
@@ -180,7 +182,7 @@ class BatchTrainer:
         noise = self.seed + self.step_index
         nstat = 8 * N.STATS_LEN
         if self.device_resident:
-            if self.dist is None or self.ws == 1:
+            if not self.multi:
                 self.eng.device_step(self.seed, first, self.n, self.replay_period, noise)
             else:
                 self.eng.device_rollout(self.seed, first, self.n, self.replay_period, self.packet.data_ptr())
@@ -193,7 +195,7 @@ class BatchTrainer:
         mask = None
         if self.replay_period > 0 and self.w.get("has_best_actions") == 1:
             mask = ((np.arange(first, first + self.n) % self.replay_period) == 0).astype(np.uint8)
-        if self.dist is None or self.ws == 1:      # one GPU: the whole step is one library call
+        if not self.multi:      # one GPU: the whole step is one library call
             improved = self.eng.train_step(self.w, self.seed, first, self.n, mask, noise_seed=noise, write_yearly=self.write_yearly)
         else:
             self.eng.upload_snapshot(self.w, write_yearly=self.write_yearly)

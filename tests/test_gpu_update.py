@@ -220,3 +220,37 @@ def test_device_resident_training_equals_host_updates(engine, world):
         assert a.lists(0) == c.lists(0) and a.get("iteration_count") == c.get("iteration_count")
     finally:
         dev.close()
+
+
+def test_rccl_path_of_the_trainer_on_one_rank():
+    """The N > 1 device-resident step (eg_device_rollout -> all_reduce -> all_gather_into_tensor -> eg_device_apply, all
+    on the stream) with the collectives really issued through RCCL (world size 1, forced) == the single-GPU step."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, hashlib
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from eirgrid_amd import synthetic_world
+from eirgrid_amd.engine import ActionWeights, Engine
+from eirgrid_amd.parallel import BatchTrainer
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29617")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+eng = Engine(synthetic_world(), device=0)
+out = []
+for forced in (False, True):
+    pol = ActionWeights()
+    tr = BatchTrainer(eng, pol, 96, 2024, 0, 1, dist, replay_fraction=0.25, force_collectives=forced)
+    for _ in range(8): tr.step()
+    tr.sync()
+    w, dw, _ = pol.tables()
+    out.append(hashlib.sha256(w.tobytes() + dw.tobytes() + bytes(sum(pol.lists(0), []))).hexdigest() + ":%%d:%%d" %% (pol.get("iteration_count"), tr.improvements))
+print("RESULT", out[0], out[1])
+dist.destroy_process_group()
+""" % root
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert line[1] == line[2] and line[1].endswith(":768:" + line[1].rsplit(":", 1)[1])
