@@ -30,7 +30,7 @@ namespace eg {
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kHelperWaves = 2;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
+constexpr int kHelperWaves = 1;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
 constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
 constexpr double kMaxWeight = 0.999;    // constants.rs:15
 constexpr double kMaxCost = 50000000000.0;   // config/constants.rs:115
@@ -1059,6 +1059,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
+    stamps[31] = t_begin;
+    // where did this workgroup run?  HW_ID (se / sh / cu / simd / wave slot) and XCC_ID: more than four workgroups on one
+    // CU means some of them had to wait for a slot (second round)
+    stamps[30] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                 ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     // diagnostic build only: cycle shares go to the (otherwise unread) tail of this episode's act_log buffer
     unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 256);
     for (int i = 0; i < 32; ++i) dbg[i] = stamps[i];

@@ -1,0 +1,29 @@
+"""Diagnostic (stamps build): per-step kernel time vs the distribution of episode cycle counts along the bench trajectory.
+   EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/bench_tail.py [B] [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from eirgrid_amd import synthetic_world
+from eirgrid_amd.engine import ActionWeights, Engine
+from eirgrid_amd.parallel import BatchTrainer
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 23
+torch.cuda.set_device(0)
+eng = Engine(synthetic_world()); pol = ActionWeights()
+tr = BatchTrainer(eng, pol, B, 12345)
+for k in range(steps):
+    eng.timing_reset(); tr.step(); eng.sync()
+    ms, n = eng.timing_read()
+    res = eng.fetch(B)
+    st = res.act_log[:, -256:].copy().view(np.uint64).astype(np.float64)
+    tot = st[:, 7]
+    srt = np.sort(tot)
+    hw = res.act_log[:, -256:].copy().view(np.uint64)[:, 30]
+    hwid = (hw & 0xFFFFFFFF).astype(np.int64); xcc = ((hw >> 32) & 0xF).astype(np.int64)
+    cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    counts = np.bincount(key.astype(np.int64))
+    counts = counts[counts > 0]
+    print(f"step {k:2d} CUs used {len(counts)}  workgroups per CU: " + " ".join(f"{c}:{int((counts == c).sum())}" for c in sorted(set(counts.tolist()))))
+    print(f"step {k:2d} kernel {ms / max(n, 1):.3f} ms  episode cycles mean {tot.mean():8.0f} p50 {srt[B // 2]:8.0f} p99 {srt[int(B * 0.99)]:8.0f} max {srt[-1]:8.0f}  "
+          f"max/2.4GHz {srt[-1] / 2.4e6:.3f} ms  placement of slowest {st[int(np.argmax(tot)), 1]:8.0f} gens {res.n_gens[int(np.argmax(tot))]}", flush=True)
