@@ -332,10 +332,14 @@ __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmc
 
 // Helper waves (kHelpers > 0, small batches only).  At B <= 4 x CUs every SIMD holds a single episode wave that is
 // latency-bound, and a launch lasts as long as its slowest episode, whose time is dominated by placement searches that
-// need several chunks.  Two more waves per episode evaluate chunks 1 and 2 of every search while the episode wave
-// evaluates chunk 0; the episode wave merges their maxima in chunk order with the same tie rule, so the winner is the
+// need several chunks.  A helper wave per episode evaluates chunk 1 of every search while the episode wave
+// evaluates chunk 0; the episode wave merges the two maxima in chunk order with the same tie rule, so the winner is the
 // one the sequential scan finds (a chunk the sequential scan would not have reached only holds candidates whose
 // unpenalised score is already below the best, so evaluating it changes nothing).
+// One helper, not more: two-wave workgroups leave the CUs a third empty, and the dispatcher needs that slack — with
+// exactly-full CUs (three-wave workgroups, 4 per CU) a few workgroups of every launch were queued behind a full CU,
+// started late and stretched the launch by a third (scripts/bench_tail.py shows the workgroups-per-CU histogram).
+// Letting the helper run further rounds (chunks 3, 5, ...) was measured too and bought nothing.
 //   protocol: episode wave writes cmd[seq & 1] and meets the helpers at a barrier; helper h evaluates chunk h and
 //   publishes {result, flag = seq}; the episode wave reads a helper's result only if that chunk's bound still reaches
 //   the best score, after spinning on its flag.  The next barrier cannot complete before every helper is back.
