@@ -1063,10 +1063,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
-    stamps[31] = t_begin;
-    // where did this workgroup run?  HW_ID (se / sh / cu / simd / wave slot) and XCC_ID: more than four workgroups on one
-    // CU means some of them had to wait for a slot (second round)
-    stamps[30] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+    // where did this workgroup run?  HW_ID (se / sh / cu / simd / wave slot) and XCC_ID: more workgroups on one CU than fit
+    // at once means some of them had to wait for a slot (second round) — scripts/bench_tail.py
+    stamps[31] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                  ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     // diagnostic build only: cycle shares go to the (otherwise unread) tail of this episode's act_log buffer
     unsigned long long* dbg = (unsigned long long*)(act_log + EG_ACT_CAP - 256);

@@ -18,7 +18,7 @@ for k in range(steps):
     st = res.act_log[:, -256:].copy().view(np.uint64).astype(np.float64)
     tot = st[:, 7]
     srt = np.sort(tot)
-    hw = res.act_log[:, -256:].copy().view(np.uint64)[:, 30]
+    hw = res.act_log[:, -256:].copy().view(np.uint64)[:, 31]
     hwid = (hw & 0xFFFFFFFF).astype(np.int64); xcc = ((hw >> 32) & 0xF).astype(np.int64)
     cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
     key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
