@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal: initialise torch.distributed and issue the per-update collectives even with one rank")
     ap.add_argument("--no-yearly", action="store_true", help="skip the 26x21 yearly rows (the reference always produces them)")
     args = ap.parse_args()
 
@@ -126,7 +128,7 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    use_dist = world_size > 1
+    use_dist = world_size > 1 or args.force_collectives
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -138,7 +140,8 @@ def main():
     eng = Engine(world, device=local_rank)
     weights = ActionWeights()
     trainer = BatchTrainer(eng, weights, args.episodes, args.seed, rank, world_size, dist if use_dist else None,
-                           replay_fraction=args.replay_fraction, write_yearly=not args.no_yearly)
+                           replay_fraction=args.replay_fraction, write_yearly=not args.no_yearly,
+                           force_collectives=args.force_collectives)
 
     def fence():
         if use_dist:

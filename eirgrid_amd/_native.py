@@ -115,7 +115,7 @@ def lib():
     L.eg_device_rollout.restype = C.c_int32
     L.eg_device_rollout.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.eg_device_apply.restype = C.c_int32
-    L.eg_device_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]
+    L.eg_device_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64]
     L.eg_device_step.restype = C.c_int32
     L.eg_device_step.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.eg_policy_pull.restype = C.c_int32

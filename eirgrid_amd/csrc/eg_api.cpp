@@ -442,10 +442,10 @@ int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   return EG_OK;
 }
 
-int32_t eg_device_apply(eg_ctx* c, void* d_stats, const void* d_candidates, int32_t n_candidates, uint64_t noise_seed) {
-  if (!c || !c->snap_valid || !d_stats || n_candidates < 0 || (n_candidates > 0 && !d_candidates)) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
+int32_t eg_device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed) {
+  if (!c || !c->snap_valid || !d_packets || n_packets < 1 || !d_own_packet) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  int lr = launch_apply_update(c->d_snap, (long long*)d_stats, d_candidates, n_candidates, noise_seed, nullptr);
+  int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, nullptr);
   if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   lr = launch_stalled_tables(c->d_snap, nullptr);
   if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -458,7 +458,7 @@ int32_t eg_device_step(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t 
   if (rc != EG_OK) return rc;
   rc = eg_device_rollout(c, seed, first_index, n, replay_period, c->d_packet);
   if (rc != EG_OK) return rc;
-  return eg_device_apply(c, c->d_packet, c->d_packet + 8 * EG_STATS_LEN, 1, noise_seed);
+  return eg_device_apply(c, c->d_packet, 1, c->d_packet, noise_seed);
 }
 
 int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {

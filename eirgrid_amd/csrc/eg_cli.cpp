@@ -226,33 +226,32 @@ int main(int argc, char** argv) {
               (unsigned long long)a.iterations, (unsigned long long)start_iteration,
               (unsigned long long)(a.iterations > start_iteration ? a.iterations - start_iteration : 0), run_dir.c_str());
 
-  void* d_packet = nullptr;
-  if (hipMalloc(&d_packet, EG_PACKET_BYTES) != hipSuccess) { std::fprintf(stderr, "hipMalloc failed\n"); return 1; }
-  std::vector<uint8_t> packet(EG_PACKET_BYTES), mask;
+  std::vector<uint8_t> mask;
   std::vector<double> metrics; std::vector<int32_t> n_run, n_def; std::vector<uint8_t> run_log, def_log;
   eg_opts opts{a.enable_energy_sales ? 1 : 0, 0, 0};
   const uint64_t final_full = a.iterations * 10 / 100;   // FULL_RUN_PERCENTAGE, multi_simulation.rs:38, :437
   auto t0 = std::chrono::steady_clock::now(); auto last_progress = t0;
   uint64_t done = start_iteration, last_checkpoint = start_iteration / a.checkpoint_interval;
+  const bool reduced = a.update == "reduced";
+  // reduced mode keeps the policy on the device: pushed once, every batch is enqueued without a host round trip and the
+  // host copy is refreshed (eg_policy_pull) when a checkpoint or a progress line needs it
+  if (reduced) CHECK(eg_policy_push(ctx, policy, &opts));
+  const uint64_t full_from = a.iterations - std::min(a.iterations, final_full);   // multi_simulation.rs:437-465
   while (done < a.iterations) {
-    const uint32_t n = uint32_t(std::min<uint64_t>(a.batch, a.iterations - done));
-    eg_policy_snapshot snap; CHECK(eg_policy_snapshot_view(policy, &snap));
-    CHECK(eg_upload_snapshot(ctx, &snap, &opts));
-    mask.assign(n, 0);
-    for (uint32_t i = 0; i < n; ++i) {   // multi_simulation.rs:437-465
-      const bool full = a.force_full_simulation || !cache_loaded || done + i >= a.iterations - std::min(a.iterations, final_full);
-      mask[i] = (full && snap.has_best && snap.best_count) ? 1 : 0;
-    }
-    if (a.update == "reduced") {
-      CHECK(eg_rollout_launch_update(ctx, a.seed, done, n, mask.data(), d_packet));
-      if (hipMemcpy(packet.data(), d_packet, EG_PACKET_BYTES, hipMemcpyDeviceToHost) != hipSuccess) { std::fprintf(stderr, "hipMemcpy failed\n"); return 1; }
-      const uint8_t* c = packet.data() + 8 * EG_STATS_LEN;
-      double score; std::memcpy(&score, c, 8);
-      const bool has = score >= 0.0;
-      CHECK(eg_policy_apply_reduced(policy, reinterpret_cast<const int64_t*>(packet.data()), has ? reinterpret_cast<const double*>(c + 16) : nullptr,
-                                    reinterpret_cast<const int32_t*>(c + 48), c + 48 + 8 * EG_YEARS,
-                                    reinterpret_cast<const int32_t*>(c + 48 + 4 * EG_YEARS), c + 48 + 8 * EG_YEARS + EG_RUN_CAP, a.seed + done));
+    uint32_t n = uint32_t(std::min<uint64_t>(a.batch, a.iterations - done));
+    const bool always_full = a.force_full_simulation || !cache_loaded;
+    if (reduced) {
+      if (!always_full && done < full_from && done + n > full_from) n = uint32_t(full_from - done);   // a batch never straddles the switch
+      const bool full = always_full || done >= full_from;
+      CHECK(eg_device_step(ctx, a.seed, done, n, full ? 1u : 0u, a.seed + done));   // replay (once a best strategy exists) when full
     } else {
+      eg_policy_snapshot snap; CHECK(eg_policy_snapshot_view(policy, &snap));
+      CHECK(eg_upload_snapshot(ctx, &snap, &opts));
+      mask.assign(n, 0);
+      for (uint32_t i = 0; i < n; ++i) {
+        const bool full = always_full || done + i >= full_from;
+        mask[i] = (full && snap.has_best && snap.best_count) ? 1 : 0;
+      }
       metrics.resize(size_t(n) * 4); n_run.resize(size_t(n) * EG_YEARS); n_def.resize(size_t(n) * EG_YEARS);
       run_log.resize(size_t(n) * EG_RUN_CAP); def_log.resize(size_t(n) * EG_DEF_CAP);
       std::vector<int32_t> status(n);
@@ -266,14 +265,17 @@ int main(int argc, char** argv) {
                                         &n_def[size_t(i) * EG_YEARS], &def_log[size_t(i) * EG_DEF_CAP], a.seed + done + i));
     }
     done += n;
-    if (done / a.checkpoint_interval != last_checkpoint || done == a.iterations) {   // multi_simulation.rs:544-567
+    const auto now = std::chrono::steady_clock::now();
+    const bool checkpoint_due = done / a.checkpoint_interval != last_checkpoint || done == a.iterations;
+    const bool progress_due = std::chrono::duration<double>(now - last_progress).count() >= double(a.progress_interval) || done == a.iterations;
+    if (reduced && (checkpoint_due || progress_due)) CHECK(eg_policy_pull(ctx, policy));
+    if (checkpoint_due) {   // multi_simulation.rs:544-567
       last_checkpoint = done / a.checkpoint_interval;
       CHECK(eg_policy_save_json(policy, (run_dir + "/thread_0_weights.json").c_str()));
       CHECK(eg_policy_save_json(policy, (run_dir + "/latest_weights.json").c_str()));
       std::ofstream(run_dir + "/checkpoint_iteration.txt") << done;
     }
-    const auto now = std::chrono::steady_clock::now();
-    if (std::chrono::duration<double>(now - last_progress).count() >= double(a.progress_interval) || done == a.iterations) {   // :303-382
+    if (progress_due) {   // :303-382
       last_progress = now;
       const double secs = std::chrono::duration<double>(now - t0).count();
       double bm[4] = {eg_policy_get_scalar(policy, 5), eg_policy_get_scalar(policy, 6), eg_policy_get_scalar(policy, 7), eg_policy_get_scalar(policy, 8)};
@@ -287,7 +289,6 @@ int main(int argc, char** argv) {
   CHECK(eg_policy_save_json(policy, (run_dir + "/best_weights.json").c_str()));   // multi_simulation.rs:1160-1164
   std::printf("Done: %llu iterations in %s; best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
               (unsigned long long)done, run_dir.c_str());
-  (void)hipFree(d_packet);
   eg_policy_free(policy);
   eg_destroy(ctx);
   return 0;

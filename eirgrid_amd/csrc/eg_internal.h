@@ -223,7 +223,7 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
                    bool helper_waves, void* ev_start, void* ev_stop);
 int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
-int launch_apply_update(uint8_t* d_snap, long long* d_stats, const void* d_cands, int n_cands, uint64_t noise_seed, void* stream);
+int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180); filled in the kernels from

@@ -1187,7 +1187,9 @@ __device__ void chacha12_block(const uint32_t* key, unsigned long long counter, 
   for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
 }
 
-__global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long long* stats, const uint8_t* cands, int n_cands,
+// `packets` = n_packets update packets of EG_PACKET_BYTES (one per rank, in rank order; the gathered copies when N > 1):
+// the statistics are summed here (integers: any order gives the same sum), the candidate records sit behind them.
+__global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const uint8_t* packets, int n_cands, long long* zero_stats,
                                                       unsigned long long noise_seed) {
   constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
   constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
@@ -1206,19 +1208,25 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
 
   // serial pieces run on different waves side by side: state + winner + "is it an improvement" on wave 1, the noise key on
   // wave 0
+  const uint8_t* cands = packets + 8 * EG_STATS_LEN;      // record r at cands + r * EG_PACKET_BYTES
+  auto stat = [&](int i) {
+    long long v = 0;
+    for (int r = 0; r < n_cands; ++r) v += reinterpret_cast<const long long*>(packets + (size_t)r * EG_PACKET_BYTES)[i];
+    return v;
+  };
   if (tid == 64) {
     st = *gstate;
     // the batch's candidate: highest score, ties to the lowest global index (eg_policy_apply_packet)
     int win = -1; double ws = 0.0; long long wi = 0;
     for (int r = 0; r < n_cands; ++r) {
-      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)r * EG_CANDIDATE_BYTES);
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)r * EG_PACKET_BYTES);
       if (c->index < 0) continue;
       if (win < 0 || c->score > ws || (c->score == ws && c->index < wi)) { win = r; ws = c->score; wi = c->index; }
     }
     s_winner = win;
     bool improved = false;
-    if (win >= 0 && stats[0] > 0) {
-      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)win * EG_CANDIDATE_BYTES);
+    if (win >= 0 && stat(0) > 0) {
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)win * EG_PACKET_BYTES);
       improved = !st.has_best || rm::score(c->metrics) > rm::score(st.best_metrics);
     }
     s_improved = improved ? 1 : 0;
@@ -1232,8 +1240,8 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
     }
   }
   __syncthreads();
-  const long long n_ok = stats[0], n_qual = stats[2];
-  const long long* pen = stats + 8; const long long* mild = stats + 8 + Y * NA; const long long* dcnt = stats + 8 + 2 * Y * NA;
+  const long long n_ok = stat(0), n_qual = stat(2);
+  constexpr int kPen = 8, kMild = 8 + Y * NA, kDcnt = 8 + 2 * Y * NA;
   const bool contrast = st.has_best && st.has_lists && n_qual > 0;
   const bool randomize_main = contrast && st.stall > 1200u;
   // the noise stream is only needed beyond 1200 stalled episodes; the deficit table may need it even if the main one
@@ -1254,7 +1262,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
       int occ = 0;
       for (int k = best_off[y]; k < best_off[y + 1]; ++k) occ += best_actions[k] == a ? 1 : 0;
       for (int k = bestd_off[y]; k < bestd_off[y + 1]; ++k) occ += bestd_actions[k] == a ? 1 : 0;
-      const double L = (double)n_qual * (double)occ * ln_boost + ((double)pen[i] + (double)mild[i]) / 4294967296.0;
+      const double L = (double)n_qual * (double)occ * ln_boost + ((double)stat(kPen + i) + (double)stat(kMild + i)) / 4294967296.0;
       double w = rm::nudge(pol[y * snap::kPolRow + a], L);
       if (randomize_main) w = rm::noise(w, draw(i));
       pol[y * snap::kPolRow + a] = w;
@@ -1268,7 +1276,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
     st.iteration_count += (uint32_t)n_ok;
     s_randomized_main = randomize_main ? 1 : 0;
     if (improved) {
-      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
+      const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_PACKET_BYTES);
       DevImprovement* log = reinterpret_cast<DevImprovement*>(snap_base + snap::imp_log) + (st.n_improvements % snap::kImpLogCap);
       log->score = rm::score(c->metrics); log->iteration = st.iteration_count; log->pad = 0;
       for (int k = 0; k < 4; ++k) { log->metrics[k] = c->metrics[k]; st.best_metrics[k] = c->metrics[k]; }
@@ -1283,7 +1291,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
   __syncthreads();
   const bool improved = s_improved != 0;
   if (improved) {      // the candidate's lists become the best lists; the main weights of this moment are kept beside them
-    const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_CANDIDATE_BYTES);
+    const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_PACKET_BYTES);
     const int nr = s_prefix[0][Y], nd = s_prefix[1][Y];
     for (int i = tid; i < nr && i < (int)snap::kBestCap; i += 1024) best_actions[i] = c->run_log[i];
     for (int i = tid; i < nd && i < (int)snap::kBestCap; i += 1024) bestd_actions[i] = c->def_log[i];
@@ -1313,7 +1321,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
           const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
           occ += slot == sl ? 1 : 0;
         }
-        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)dcnt[i] * dc.ln_pen;
+        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)stat(kDcnt + i) * dc.ln_pen;
         double w = rm::nudge(pol[y * snap::kPolRow + snap::kPolDw + sl], L);
         if (randomize) w = rm::noise(w, draw(first_draw + i));
         pol[y * snap::kPolRow + snap::kPolDw + sl] = w;
@@ -1331,7 +1339,10 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, long 
     row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
   }
   if (tid == 64) { rm::derive_state(st); *gstate = st; }            // beside the row sums of wave 0
-  for (int i = tid; i < EG_STATS_LEN; i += 1024) stats[i] = 0;      // ready for the next batch's epilogue
+  // this rank's statistics buffer is ready for the next batch's epilogue (when it is also `packets`, every read of it
+  // happened before the barriers above)
+  __syncthreads();
+  for (int i = tid; i < EG_STATS_LEN; i += 1024) zero_stats[i] = 0;
 }
 
 }  // namespace
@@ -1360,9 +1371,9 @@ int launch_stalled_tables(uint8_t* d_snap, void* stream) {
   hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap);
   return (int)hipGetLastError();
 }
-int launch_apply_update(uint8_t* d_snap, long long* d_stats, const void* d_cands, int n_cands, uint64_t noise_seed, void* stream) {
-  hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, d_stats, (const uint8_t*)d_cands, n_cands,
-                     (unsigned long long)noise_seed);
+int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed, void* stream) {
+  hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, (const uint8_t*)d_packets, n_packets,
+                     d_zero_stats, (unsigned long long)noise_seed);
   return (int)hipGetLastError();
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {

@@ -304,8 +304,8 @@ class Engine:
         N.check(N.lib().eg_device_rollout(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index), n_episodes,
                                           replay_period, C.c_void_p(d_packet_ptr)), "eg_device_rollout")
 
-    def device_apply(self, d_stats_ptr: int, d_candidates_ptr: int, n_candidates: int, noise_seed: int):
-        N.check(N.lib().eg_device_apply(self.h, C.c_void_p(d_stats_ptr), C.c_void_p(d_candidates_ptr), n_candidates,
+    def device_apply(self, d_packets_ptr: int, n_packets: int, d_own_packet_ptr: int, noise_seed: int):
+        N.check(N.lib().eg_device_apply(self.h, C.c_void_p(d_packets_ptr), n_packets, C.c_void_p(d_own_packet_ptr),
                                         C.c_uint64(noise_seed & (2**64 - 1))), "eg_device_apply")
 
     def device_step(self, seed: int, first_episode_index: int, n_episodes: int, replay_period: int, noise_seed: int):

@@ -157,7 +157,7 @@ class BatchTrainer:
         self._improvements_host = 0
         if self.device_resident:
             if multi:
-                self.gathered = torch.zeros(world_size * N.CANDIDATE_BYTES, dtype=torch.uint8, device=self.device)
+                self.gathered = torch.zeros(world_size * N.PACKET_BYTES, dtype=torch.uint8, device=self.device)
             self.eng.push(weights, write_yearly=write_yearly)
 
     @property
@@ -186,10 +186,10 @@ class BatchTrainer:
                 self.eng.device_step(self.seed, first, self.n, self.replay_period, noise)
             else:
                 self.eng.device_rollout(self.seed, first, self.n, self.replay_period, self.packet.data_ptr())
-                stats = self.packet[:nstat].view(self.torch.int64)
-                self.dist.all_reduce(stats, op=self.dist.ReduceOp.SUM)      # the one all-reduce of the update (RCCL over xGMI)
-                self.dist.all_gather_into_tensor(self.gathered, self.packet[nstat:])
-                self.eng.device_apply(self.packet.data_ptr(), self.gathered.data_ptr(), self.ws, noise)
+                # the one collective of the update (RCCL over xGMI): every rank receives every rank's 32 KB packet; the
+                # statistics are integers, so summing them inside k_apply_update is the all-reduce
+                self.dist.all_gather_into_tensor(self.gathered, self.packet)
+                self.eng.device_apply(self.gathered.data_ptr(), self.ws, self.packet.data_ptr(), noise)
             self.step_index += 1
             return None
         mask = None

@@ -224,17 +224,18 @@ int32_t eg_train_step(eg_ctx *, eg_policy *, const eg_opts *opts, uint64_t seed,
                       uint32_t n_episodes, const uint8_t *replay_mask /* host, may be NULL */, uint64_t noise_seed);
 /* Device-resident policy.  eg_policy_push uploads the policy once; after that every training step runs on the device with
  * no host synchronisation: eg_device_rollout enqueues the rollout (statistics epilogue, best pick) into `d_packet`
- * (DEVICE, EG_PACKET_BYTES, zeroed once by the caller), eg_device_apply enqueues the batch update from the summed
- * statistics and n_candidates candidate records (DEVICE pointers; between the two calls a multi-GPU caller all-reduces the
- * statistics part and all-gathers the candidate records on the same stream) and zeroes the statistics for the next step.
- * eg_device_step does both on a library-owned packet (one GPU).  The update is the one of eg_policy_apply_packet, bit for
- * bit (both evaluate csrc/eg_reduced_math.h).  replay_period > 0: episode with global index i replays the best strategy
- * when i % replay_period == 0 and a best strategy exists (decided on the device).  eg_policy_pull waits for the stream
- * and copies the policy back into `policy` (tables, best strategy, counters, improvement history). */
+ * (DEVICE, EG_PACKET_BYTES, zeroed once by the caller); eg_device_apply enqueues the batch update from n_packets update
+ * packets laid out back to back (DEVICE; with one GPU that is d_packet itself, with N GPUs the result of ONE all-gather of
+ * every rank's packet on the same stream — the statistics are integer sums, so adding them up in the kernel is the
+ * all-reduce) and zeroes the statistics of `d_own_packet` for the next step.  eg_device_step does both on a
+ * library-owned packet (one GPU).  The update is the one of eg_policy_apply_packet, bit for bit (both evaluate
+ * csrc/eg_reduced_math.h).  replay_period > 0: the episode with global index i replays the best strategy when
+ * i % replay_period == 0 and a best strategy exists (decided on the device).  eg_policy_pull waits for the stream and
+ * copies the policy back into `policy` (tables, best strategy, counters, improvement history). */
 int32_t eg_policy_push(eg_ctx *, const eg_policy *, const eg_opts *opts);
 int32_t eg_device_rollout(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
                           void *d_packet);
-int32_t eg_device_apply(eg_ctx *, void *d_stats, const void *d_candidates, int32_t n_candidates, uint64_t noise_seed);
+int32_t eg_device_apply(eg_ctx *, const void *d_packets, int32_t n_packets, void *d_own_packet, uint64_t noise_seed);
 int32_t eg_device_step(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
                        uint64_t noise_seed);
 int32_t eg_policy_pull(eg_ctx *, eg_policy *);

@@ -254,3 +254,40 @@ dist.destroy_process_group()
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert line[1] == line[2] and line[1].endswith(":768:" + line[1].rsplit(":", 1)[1])
+
+
+def test_device_update_from_two_rank_packets(engine, world):
+    """k_apply_update with two update packets (what an all-gather delivers on two ranks: each rank's shard statistics and
+    candidate) == the host update from the summed statistics and both candidate records."""
+    from eirgrid_amd.engine import Engine, apply_packet
+    dev = Engine(world, device=0)
+    try:
+        a, b = ActionWeights(), ActionWeights()
+        n = 96                                    # episodes per "rank"
+        PB, nstat = N.PACKET_BYTES, 8 * N.STATS_LEN
+        packets = torch.zeros(2 * PB, dtype=torch.uint8, device="cuda")
+        hostp = torch.zeros(PB, dtype=torch.uint8, device="cuda")
+        dev.push(b)
+        for step in range(10):
+            first = step * 2 * n
+            # host side: the two shards one after the other against the same snapshot, statistics added, both candidates kept
+            engine.upload_snapshot(a)
+            stats = np.zeros(N.STATS_LEN, np.int64); cands = []
+            for r in range(2):
+                engine.launch_update(31, first + r * n, n, hostp.data_ptr(), None)
+                h = hostp.cpu().numpy()
+                stats += h[:nstat].view(np.int64); cands.append(h[nstat:].copy())
+            apply_packet(a, stats, np.stack(cands), noise_seed=70 + step)
+            # device side: "rank" r writes packet r, then one update from both
+            for r in range(2):
+                dev.device_rollout(31, first + r * n, n, 0, packets.data_ptr() + r * PB)
+            dev.device_apply(packets.data_ptr(), 2, packets.data_ptr(), 70 + step)
+            packets[PB:PB + nstat] = 0            # the second rank's own statistics (its own k_apply_update zeroes them)
+            dev.pull(b)
+            for x, y in zip(a.tables(), b.tables()):
+                assert x.tobytes() == y.tobytes(), f"step {step}"
+            assert a.lists(0) == b.lists(0) and a.lists(1) == b.lists(1)
+            assert a.get("iterations_without_improvement") == b.get("iterations_without_improvement")
+            assert a.get("iteration_count") == b.get("iteration_count") == (step + 1) * 2 * n
+    finally:
+        dev.close()
