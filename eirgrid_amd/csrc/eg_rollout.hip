@@ -277,14 +277,19 @@ __device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed) {
   return __builtin_amdgcn_sdot2(d, stride, 0, false);
 }
 
-// Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
-__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
-                                              double cf, int cell) {
+// A search multiplies te by the factor of every generator, in list order.  Searches of the same (year, variant) revisit
+// the same candidates while the list only grows at its end, so the running product of a chunk is kept between searches
+// and a later search of that (year, variant) continues it with the generators added since — the same multiplications in
+// the same order, hence the same bits.  (Years with many additions — the slow episodes — mostly repeat one variant.)
+struct PrefixCache { double product; int key; int count; };      // key: year << 8 | variant, -1 = empty; count: generators folded in
+
+// s_init times the factors of generators [k0, ngen_s) for this lane's candidate cell
+__device__ __forceinline__ double chunk_product(const double* dr, int lane, int k0, int ngen_s, double s_init, int cell) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
-  double s = te;
+  double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
   const char* drb = reinterpret_cast<const char*>(dr);
-  for (int gb = 0; gb < ngen_s; gb += kWave) {                    // generators in list order
+  for (int gb = k0; gb < ngen_s; gb += kWave) {                   // generators in list order
     // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
     const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
     const int mi = mine / kGrid;
@@ -305,6 +310,21 @@ __device__ __forceinline__ double chunk_score(const double* dr, double size_fact
     s = s * f0; s = s * f1; s = s * f2; s = s * f3;
 #undef EG_FACTOR
   }
+  return s;
+}
+// Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
+__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
+                                              double cf, int cell) {
+  const double s = (chunk_product(dr, lane, 0, ngen_s, te, cell) * cf) * size_factor;
+  return r < kCells ? s : 0.0;
+}
+// ... continuing the product kept from the last search of the same (year, variant) when there is one
+__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
+                                              double cf, int cell, PrefixCache& cache, int key) {
+  double s = te; int k0 = 0;
+  if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
+  s = chunk_product(dr, lane, k0, ngen_s, s, cell);
+  cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
@@ -345,6 +365,7 @@ __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmc
 //   the best score, after spinning on its flag.  The next barrier cannot complete before every helper is back.
 __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h) {
   const double size_factor = T.size_factor;
+  PrefixCache cache = {0.0, -1, 0};
   for (uint32_t sq = 1;; ++sq) {
     wg_barrier_lds();
     const int c0 = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][0]);
@@ -360,7 +381,7 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long th1 = __builtin_readcyclecounter();
 #endif
-    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell);
+    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v);
 #ifdef EG_STAMPS
     const unsigned long long th2 = __builtin_readcyclecounter();
 #endif
@@ -376,7 +397,8 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
 
 template <int kHelpers>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
-                                            double* best_m03, uint32_t* seq = nullptr, unsigned long long* stamps = nullptr) {
+                                            double* best_m03, PrefixCache& cache0, uint32_t* seq = nullptr,
+                                            unsigned long long* stamps = nullptr) {
   const int info = sm.type_info[type];
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
@@ -402,7 +424,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell);
+    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell, cache0, (yi << 8) | v);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
@@ -442,6 +464,9 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
+    // the single-wave kernel keeps the products of chunks 0 and 1, the episode wave of the helper kernel that of chunk 0
+    // (the kept products are used by the small-batch kernel only: in the throughput kernel the extra live registers cost
+    //  more than the shorter loops give back)
     const double s = chunk_score(dr, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
@@ -694,6 +719,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
   uint32_t search_seq = 0;
+  PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave > 0) { helper_loop(T, lane, wave); return; }
@@ -941,11 +967,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
-        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, &search_seq, stamps);
+        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq, stamps);
         stamps[11] += 1;
 #else
         double m03v = 0.0;
-        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, &search_seq);
+        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq);
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
@@ -1092,7 +1118,8 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   load_static_tables(T, lane);
   __syncthreads();
   double score = 0.0;
-  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr);
+  PrefixCache pc0 = {0.0, -1, 0};
+  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr, pc0);
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
