@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <ctime>
 #include <fstream>
 #include <memory>
 #include <sstream>
@@ -173,6 +175,77 @@ int32_t eg_policy_save_json(const eg_policy* p, const char* path) {   // ai/lear
   std::ofstream f(path, std::ios::binary | std::ios::trunc);
   if (!f) { eg::set_error(std::string("eg_policy_save_json: cannot open ") + path); return EG_ERR_BAD_ARG; }
   f << w.out;
+  return f.good() ? EG_OK : EG_ERR_BAD_ARG;
+}
+
+// --track-weight-history (core/multi_simulation.rs:166-207, :557-560): weight_history.json is a pretty-printed array that
+// gains one snapshot {best_score, iteration, timestamp, weights: ActionWeights::to_json()} per checkpoint.  serde_json's
+// Map is a BTreeMap here (no preserve_order feature, Cargo.toml:11), so every object lists its keys in byte order; the
+// table keys are the Display strings of the actions (ai/actions/grid_action.rs:18-41).
+int32_t eg_policy_append_weight_history(const eg_policy* p, const char* path, uint64_t iteration) {
+  if (!p || !path) return EG_ERR_BAD_ARG;
+  auto display = [](int a) {
+    if (a < 45) return std::string("AddGenerator(") + kTypeName[a / 3] + ", " + std::to_string(kMultPercent[a % 3]) + "%)";
+    if (a < 57) return std::string("AddCarbonOffset(") + kOffsetName[(a - 45) / 3] + ", " + std::to_string(kMultPercent[(a - 45) % 3]) + "%)";
+    if (a == 57) return std::string("UpgradeEfficiency()");
+    if (a == 58) return std::string("AdjustOperation(, 0%)");
+    if (a == 59) return std::string("CloseGenerator()");
+    return std::string("DoNothing");
+  };
+  Writer w; w.depth = 1;
+  auto sorted_table = [&](int n, auto key_of, auto value_of) {      // {"2025": {key: value, ...}, ...}, keys in byte order
+    w.out += '{'; ++w.depth;
+    for (int y = 0; y < Y; ++y) {
+      std::vector<std::pair<std::string, double>> kv;
+      for (int i = 0; i < n; ++i) kv.emplace_back(key_of(i), value_of(y, i));
+      std::sort(kv.begin(), kv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      w.nl(); w.out += "\"" + std::to_string(2025 + y) + "\": {"; ++w.depth;
+      for (size_t i = 0; i < kv.size(); ++i) { w.nl(); w.out += "\"" + kv[i].first + "\": " + fmt_f64(kv[i].second); if (i + 1 < kv.size()) w.out += ','; }
+      --w.depth; w.nl(); w.out += '}';
+      if (y + 1 < Y) w.out += ',';
+    }
+    --w.depth; w.nl(); w.out += '}';
+  };
+  const double best_score = p->has_best ? eg_score_metrics(p->best_metrics.data(), 0) : 0.0;
+  char stamp[64];
+  {  // chrono Local::now().to_rfc3339(): nanoseconds and the local UTC offset
+    timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    std::tm tmv; localtime_r(&ts.tv_sec, &tmv);
+    char date[32]; std::strftime(date, sizeof(date), "%Y-%m-%dT%H:%M:%S", &tmv);
+    const long off = tmv.tm_gmtoff; const long ao = off < 0 ? -off : off;
+    std::snprintf(stamp, sizeof(stamp), "%s.%09ld%c%02ld:%02ld", date, ts.tv_nsec, off < 0 ? '-' : '+', ao / 3600, (ao / 60) % 60);
+  }
+  w.nl(); w.out += '{'; ++w.depth;
+  w.nl(); w.out += "\"best_score\": " + fmt_f64(best_score) + ",";
+  w.nl(); w.out += "\"iteration\": " + std::to_string(iteration) + ",";
+  w.nl(); w.out += std::string("\"timestamp\": \"") + stamp + "\",";
+  w.nl(); w.out += "\"weights\": {"; ++w.depth;
+  w.nl(); w.out += "\"action_count_weights\": ";
+  if (p->has_cw) sorted_table(NC, [](int i) { return std::to_string(i); }, [&](int y, int i) { return p->cw[y][i]; }); else w.out += "{}";
+  w.out += ',';
+  w.nl(); w.out += "\"best_score\": " + fmt_f64(best_score) + ",";
+  w.nl(); w.out += "\"deficit_weights\": "; sorted_table(ND, [&](int i) { return display(kDeficitAction[i]); }, [&](int y, int i) { return p->dw[y][i]; }); w.out += ',';
+  w.nl(); w.out += "\"exploration_rate\": " + fmt_f64(p->exploration_rate) + ",";
+  w.nl(); w.out += "\"force_best_actions\": false,";
+  w.nl(); w.out += "\"guaranteed_best_actions\": false,";
+  w.nl(); w.out += "\"iteration_count\": " + std::to_string(p->iteration_count) + ",";
+  w.nl(); w.out += "\"iterations_without_improvement\": " + std::to_string(p->stall) + ",";
+  w.nl(); w.out += "\"learning_rate\": " + fmt_f64(p->learning_rate) + ",";
+  w.nl(); w.out += "\"optimization_mode\": null,";
+  w.nl(); w.out += "\"weights\": "; sorted_table(NA, display, [&](int y, int i) { return p->w[y][i]; });
+  --w.depth; w.nl(); w.out += '}';
+  --w.depth; w.nl(); w.out += '}';
+  // the file is "[]" or "[\n  {...},\n  {...}\n]": append in place instead of re-parsing the whole history
+  std::string text;
+  { std::ifstream f(path, std::ios::binary); if (f) { std::stringstream ss; ss << f.rdbuf(); text = ss.str(); } }
+  size_t end = text.find_last_of(']');
+  std::string head = end == std::string::npos ? std::string("[") : text.substr(0, end);
+  while (!head.empty() && (head.back() == '\n' || head.back() == ' ')) head.pop_back();
+  const bool empty = head == "[" || head.empty();
+  if (head.empty()) head = "[";
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) { eg::set_error(std::string("eg_policy_append_weight_history: cannot open ") + path); return EG_ERR_BAD_ARG; }
+  f << head << (empty ? "" : ",") << w.out << "\n]";
   return f.good() ? EG_OK : EG_ERR_BAD_ARG;
 }
 

@@ -273,6 +273,7 @@ int main(int argc, char** argv) {
       last_checkpoint = done / a.checkpoint_interval;
       CHECK(eg_policy_save_json(policy, (run_dir + "/thread_0_weights.json").c_str()));
       CHECK(eg_policy_save_json(policy, (run_dir + "/latest_weights.json").c_str()));
+      if (a.track_weight_history) CHECK(eg_policy_append_weight_history(policy, (run_dir + "/weight_history.json").c_str(), done - 1));   // :557-560
       std::ofstream(run_dir + "/checkpoint_iteration.txt") << done;
     }
     if (progress_due) {   // :303-382

@@ -243,7 +243,10 @@ int32_t eg_policy_pull(eg_ctx *, eg_policy *);
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */
 int32_t eg_policy_save_json(const eg_policy *, const char *path);
-eg_policy *eg_policy_load_json(const char *path);   /* NULL + eg_last_error() on failure */
+eg_policy *eg_policy_load_json(const char *path);
+/* --track-weight-history (core/multi_simulation.rs:166-207): append one snapshot {best_score, iteration, timestamp,
+ * weights: ActionWeights::to_json()} to the pretty-printed JSON array in `path` (created as needed). */
+int32_t eg_policy_append_weight_history(const eg_policy *, const char *path, uint64_t iteration);   /* NULL + eg_last_error() on failure */
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus

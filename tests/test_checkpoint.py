@@ -85,3 +85,36 @@ def test_loads_a_reference_style_file(tmp_path, built):
         ActionWeights.load_from_file(tmp_path / "c.json")
     with pytest.raises(N.EirgridError):
         ActionWeights.load_from_file(tmp_path / "missing.json")
+
+
+def test_weight_history_snapshots(built, tmp_path):
+    """--track-weight-history: weight_history.json is a JSON array that grows by one ActionWeights::to_json() snapshot per
+    checkpoint; objects list their keys in byte order (serde_json's BTreeMap), table keys are the actions' Display strings."""
+    import json
+    from eirgrid_amd import _native as N
+    from eirgrid_amd.engine import ActionWeights
+    pol = ActionWeights()
+    path = str(tmp_path / "weight_history.json")
+    (tmp_path / "weight_history.json").write_text("[]")            # the reference creates it like this
+    for it in (4, 9, 14):
+        N.check(N.lib().eg_policy_append_weight_history(pol.h, path.encode(), it))
+    text = open(path).read()
+    hist = json.loads(text)
+    assert [h["iteration"] for h in hist] == [4, 9, 14]
+    snap = hist[0]
+    assert list(snap.keys()) == sorted(snap.keys()) == ["best_score", "iteration", "timestamp", "weights"]
+    w = snap["weights"]
+    assert list(w.keys()) == sorted(w.keys())
+    assert set(w.keys()) == {"action_count_weights", "best_score", "deficit_weights", "exploration_rate", "force_best_actions",
+                             "guaranteed_best_actions", "iteration_count", "iterations_without_improvement", "learning_rate",
+                             "optimization_mode", "weights"}
+    y = w["weights"]["2025"]
+    assert len(y) == 61 and list(y.keys()) == sorted(y.keys())
+    assert "AddGenerator(OnshoreWind, 100%)" in y and "AddCarbonOffset(Forest, 150%)" in y and "AdjustOperation(, 0%)" in y and "DoNothing" in y
+    table, _, counts = pol.tables()
+    assert y["AddGenerator(OnshoreWind, 100%)"] == table[0, 0] and y["DoNothing"] == table[0, 60]
+    assert list(w["action_count_weights"]["2030"].keys()) == sorted(str(i) for i in range(21))
+    assert w["action_count_weights"]["2030"]["7"] == counts[5, 7]
+    assert len(w["deficit_weights"]["2050"]) == 15 and "AddGenerator(GasPeaker, 100%)" in w["deficit_weights"]["2050"]
+    assert text.startswith("[\n  {\n    \"best_score\": 0.0,\n    \"iteration\": 4,") and text.endswith("\n  }\n]")
+    assert snap["timestamp"][10] == "T" and snap["timestamp"][-6] in "+-"
