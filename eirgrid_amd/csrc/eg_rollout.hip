@@ -30,6 +30,7 @@ namespace eg {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kCmdYear = 1 << 30;       // helper command: fold next year's starting sums (else: a placement search)
 constexpr int kHelperWaves = 1;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
 constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
 constexpr double kMaxWeight = 0.999;    // constants.rs:15
@@ -63,6 +64,8 @@ struct __align__(16) Smem {
   // helper waves (small-batch kernel only): search command (double-buffered by sequence parity), results, flags
   int cmd[2][2];                      // {year | variant << 8 | radius class << 12 (or -1: exit), generators in the list}
   uint32_t hflag[2];                  // sequence number of the search whose result is in hres[h]
+  uint32_t yflag; int ysum_opcnt;     // year-start sums folded by the helper wave (sequence number, count)
+  double ysum[8];                     //   gcost, optot, offs, ocost, co2, tg, ig, sg
   struct { double score, m03; int cell, pad; } hres[2];
 #ifdef EG_STAMPS
   unsigned long long hdbg[2][4];
@@ -350,6 +353,84 @@ __device__ __forceinline__ ChunkBest chunk_reduce(double s, int cell, double m03
 // Workgroup barrier that orders LDS only: the episode's output stores and table loads stay in flight across it.
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- aggregates at the start of a year: existing plant first (host tables), then every generator in list order.
+//      The lanes gather the per-generator terms in parallel (year_gather: requests only); the sums are then folded lane
+//      by lane with readlane, i.e. in list order (year_fold).  Output / CO2 terms of a plant never change (delays off),
+//      so the class sums carry over from the end of last year whenever the existing-plant prefix did (`carry`), bit for
+//      bit; otherwise they are folded here as well. ----
+struct YearTerms { double2 g_cc; double g_m03, g_t12, o_v, o_c; int g_t; };
+struct YearSums { double gcost, optot, offs, ocost, co2, tg, ig, sg; int opcnt; };
+
+__device__ __forceinline__ void year_gather_gens(const DevTables& T, int lane, int yi, int base, int ngen_s, YearTerms& t) {
+  const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
+  const int g = base + lane;
+  const bool valid = g < ngen_s;
+  const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
+  const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
+  t.g_t = gc >> 12;
+  t.g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t.g_t * kYears + b) * kMults + m) * 2);
+  t.g_m03 = T.m03()[cell]; t.g_t12 = T.t12()[(size_t)yi * kTypes + t.g_t];
+}
+__device__ __forceinline__ void year_gather_offsets(const DevTables& T, int lane, int yi, int base, int noff_s, YearTerms& t) {
+  const int k = base + lane;
+  const int p = k < noff_s ? sm.opack[k] : 0;
+  const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+  t.o_v = T.offv()[((size_t)yi * kOffsetTypes + ot) * kYears + b]; t.o_c = T.offc()[((size_t)yi * kOffsetTypes + ot) * kMults + m];
+}
+// the first 64 entries of each list are requested here; year_fold gathers the rest (rare) itself
+__device__ __forceinline__ YearTerms year_gather(const DevTables& T, int lane, int yi, int ngen_s, int noff_s) {
+  YearTerms t; t.g_cc.x = 0.0; t.g_cc.y = 0.0; t.g_m03 = 0.0; t.g_t12 = 0.0; t.o_v = 0.0; t.o_c = 0.0; t.g_t = 0;
+  if (ngen_s > 0) year_gather_gens(T, lane, yi, 0, ngen_s, t);
+  if (noff_s > 0) year_gather_offsets(T, lane, yi, 0, noff_s, t);
+  return t;
+}
+// `s` comes in holding the starting values (0 / the existing-plant prefix) and leaves holding the year-start sums
+__device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, int ngen_s, int noff_s, bool carry, YearTerms t,
+                                          YearSums& s) {
+  for (int base = 0; base < ngen_s; base += kWave) {
+    if (base > 0) year_gather_gens(T, lane, yi, base, ngen_s, t);      // beyond the first 64 generators (rare)
+    const double2 cc = t.g_cc;
+    const int ty = t.g_t;
+    const double op = (t.g_m03 + t.g_t12) + cc.y;
+    double out = 0.0, co2 = 0.0; int cls = 0;
+    if (!carry) { out = sm.type_out[ty]; co2 = sm.type_co2[ty]; cls = (sm.type_info[ty] >> 12) & 3; }
+    const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
+    if (carry) {            // the common year: two independent chains, four generators per trip
+      int j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const double c0 = readlane_f64(cc.x, j), c1 = readlane_f64(cc.x, j + 1), c2 = readlane_f64(cc.x, j + 2), c3 = readlane_f64(cc.x, j + 3);
+        const double o0 = readlane_f64(op, j), o1 = readlane_f64(op, j + 1), o2 = readlane_f64(op, j + 2), o3 = readlane_f64(op, j + 3);
+        s.gcost += c0; s.optot += o0; s.gcost += c1; s.optot += o1; s.gcost += c2; s.optot += o2; s.gcost += c3; s.optot += o3;
+      }
+      for (; j < cnt; ++j) { s.gcost += readlane_f64(cc.x, j); s.optot += readlane_f64(op, j); }
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        s.gcost += readlane_f64(cc.x, j);
+        s.optot += readlane_f64(op, j);
+        const double oj = readlane_f64(out, j);
+        const int cj = __builtin_amdgcn_readlane(cls, j);
+        s.co2 += readlane_f64(co2, j);
+        if (cj == 1) s.ig += oj; else if (cj == 2) s.sg += oj; else s.tg += oj;
+      }
+    }
+    s.opcnt += cnt;
+  }
+  for (int base = 0; base < noff_s; base += kWave) {
+    if (base > 0) year_gather_offsets(T, lane, yi, base, noff_s, t);
+    const double ov = t.o_v, oc = t.o_c;
+    const int cnt = noff_s - base < kWave ? noff_s - base : kWave;
+    for (int j = 0; j < cnt; ++j) { s.offs += readlane_f64(ov, j); s.ocost += readlane_f64(oc, j); }
+  }
+}
+// starting values of the sums for year yi: zero, or the existing-plant prefix of that year (class sums only when they
+// do not carry over)
+__device__ __forceinline__ YearSums year_sums_init(int yi) {
+  YearSums s;
+  s.gcost = 0.0; s.ocost = 0.0; s.offs = 0.0; s.optot = sm.yr[4][yi]; s.opcnt = sm.yr_opcnt[yi];
+  s.co2 = sm.yr[0][yi]; s.tg = sm.yr[1][yi]; s.ig = sm.yr[2][yi]; s.sg = sm.yr[3][yi];
+  return s;
+}
+
 // Helper waves (kHelpers > 0, small batches only).  At B <= 4 x CUs every SIMD holds a single episode wave that is
 // latency-bound, and a launch lasts as long as its slowest episode, whose time is dominated by placement searches that
 // need several chunks.  A helper wave per episode evaluates chunk 1 of every search while the episode wave
@@ -371,6 +452,19 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     const int c0 = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][0]);
     const int ngen_s = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][1]);
     if (c0 < 0) return;
+    if (c0 & kCmdYear) {      // next year's starting sums (year_fold), while the episode wave closes the current year
+      const int yi = c0 & 31, ngen = ngen_s & 0xFFFF, noff = (ngen_s >> 16) & 0xFFFF;
+      const bool carry = ((c0 >> 8) & 1) != 0;
+      YearSums ys = year_sums_init(yi);
+      year_fold(T, lane, yi, ngen, noff, carry, year_gather(T, lane, yi, ngen, noff), ys);
+      if (lane == 0) {
+        sm.ysum[0] = ys.gcost; sm.ysum[1] = ys.optot; sm.ysum[2] = ys.offs; sm.ysum[3] = ys.ocost;
+        sm.ysum[4] = ys.co2; sm.ysum[5] = ys.tg; sm.ysum[6] = ys.ig; sm.ysum[7] = ys.sg; sm.ysum_opcnt = ys.opcnt;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *(volatile uint32_t*)&sm.yflag = sq;
+      continue;
+    }
     const int yi = c0 & 31, v = (c0 >> 8) & 15, rc = (c0 >> 12) & 15;
     const int r = h * kWave + lane;
 #ifdef EG_STAMPS
@@ -718,7 +812,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t e = blockIdx.x;
   if (e >= n_episodes) return;
-  uint32_t search_seq = 0;
+  uint32_t search_seq = 0, year_seq = 0;      // commands to the helper wave share one sequence
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -766,27 +860,14 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
     EG_MARKG(17);
-    // ---- requests first: the per-generator / per-offset terms of this year (first 64 of each list) ----
-    const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
-    const double* t12y = T.t12() + (size_t)yi * kTypes;
-    const double* offvy = T.offv() + (size_t)yi * kOffsetTypes * kYears;
-    const double* offcy = T.offc() + (size_t)yi * kOffsetTypes * kMults;
+    // ---- requests first: the per-generator / per-offset terms of this year (first 64 of each list).  In the small-batch
+    //      kernel the helper wave was asked for this year's sums when last year's actions ended (see below). ----
     const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
     const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
-    double2 g_cc = {0.0, 0.0}; double g_m03 = 0.0, g_t12 = 0.0, o_v = 0.0, o_c = 0.0; int g_t = 0;
-    if (ngen_s > 0) {
-      const bool valid = lane < ngen_s;
-      const int gc = valid ? sm.gcell[lane] : 0, bm = valid ? sm.gbm[lane] : 0;
-      const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
-      g_t = gc >> 12;
-      g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(g_t * kYears + b) * kMults + m) * 2);
-      g_m03 = T.m03()[cell]; g_t12 = t12y[g_t];
-    }
-    if (noff_s > 0) {
-      const int p = lane < noff_s ? sm.opack[lane] : 0;
-      const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
-      o_v = offvy[ot * kYears + b]; o_c = offcy[ot * kMults + m];
-    }
+    const bool carry = ((carry_mask >> yi) & 1u) != 0u;
+    const bool sums_from_helper = kHelpers > 0 && yi > 0;
+    YearTerms terms;
+    if (!sums_from_helper) terms = year_gather(T, lane, yi, ngen_s, noff_s);
     {  // this year's policy block -> LDS (requested a year ahead), then request next year's
     wave_sync();
     sm.pol[lane] = np0; sm.pol[64 + lane] = np1;
@@ -804,68 +885,25 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     const double cw_total = sm.pol[snap::kPolTotCount];
     EG_TE(14);
 
-    // ---- aggregates at the start of the year: existing plant first, then every generator in list order.
-    //      The lanes gather the per-generator terms in parallel; the sums are then folded lane by lane (readlane),
-    //      i.e. in list order.  Output / CO2 terms of a plant never change (delays off), so those three sums carry
-    //      over from the end of last year whenever the existing-plant prefix did, bit for bit. ----
+    // ---- aggregates at the start of the year (year_gather / year_fold above) ----
     Agg a;
     a.usage = sm.yr[5][yi];
-    a.gcost = 0.0; a.ocost = 0.0; a.offs = 0.0;
     a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
-    a.optot = sm.yr[4][yi]; a.opcnt = sm.yr_opcnt[yi];
     {
       EG_MARKG(18);
-      const double pco2 = sm.yr[0][yi], ptg = sm.yr[1][yi], pig = sm.yr[2][yi], psg = sm.yr[3][yi];
-      const bool carry = ((carry_mask >> yi) & 1u) != 0u;
+      YearSums ys;
+      if (sums_from_helper) {      // folded by the helper wave while this wave closed last year
+        while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.yflag) != (int)year_seq) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        ys.gcost = sm.ysum[0]; ys.optot = sm.ysum[1]; ys.offs = sm.ysum[2]; ys.ocost = sm.ysum[3];
+        ys.co2 = sm.ysum[4]; ys.tg = sm.ysum[5]; ys.ig = sm.ysum[6]; ys.sg = sm.ysum[7]; ys.opcnt = sm.ysum_opcnt;
+      } else {
+        ys = year_sums_init(yi);
+        year_fold(T, lane, yi, ngen_s, noff_s, carry, terms, ys);
+      }
+      a.gcost = ys.gcost; a.optot = ys.optot; a.offs = ys.offs; a.ocost = ys.ocost; a.opcnt = ys.opcnt;
       if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
-      else { a.co2 = pco2; a.tg = ptg; a.ig = pig; a.sg = psg; }
-      for (int base = 0; base < ngen_s; base += kWave) {
-        if (base > 0) {      // beyond the first 64 generators (rare): same gather, inline
-          const int g = base + lane;
-          const bool valid = g < ngen_s;
-          const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
-          const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
-          g_t = gc >> 12;
-          g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(g_t * kYears + b) * kMults + m) * 2);
-          g_m03 = T.m03()[cell]; g_t12 = t12y[g_t];
-        }
-        const double2 cc = g_cc;
-        const int t = g_t;
-        const double op = (g_m03 + g_t12) + cc.y;
-        double out = 0.0, co2 = 0.0; int cls = 0;
-        if (!carry) { out = sm.type_out[t]; co2 = sm.type_co2[t]; cls = (sm.type_info[t] >> 12) & 3; }
-        const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
-        if (carry) {            // the common year: two independent chains, four generators per trip
-          int j = 0;
-          for (; j + 4 <= cnt; j += 4) {
-            const double c0 = readlane_f64(cc.x, j), c1 = readlane_f64(cc.x, j + 1), c2 = readlane_f64(cc.x, j + 2), c3 = readlane_f64(cc.x, j + 3);
-            const double o0 = readlane_f64(op, j), o1 = readlane_f64(op, j + 1), o2 = readlane_f64(op, j + 2), o3 = readlane_f64(op, j + 3);
-            a.gcost += c0; a.optot += o0; a.gcost += c1; a.optot += o1; a.gcost += c2; a.optot += o2; a.gcost += c3; a.optot += o3;
-          }
-          for (; j < cnt; ++j) { a.gcost += readlane_f64(cc.x, j); a.optot += readlane_f64(op, j); }
-        } else {
-          for (int j = 0; j < cnt; ++j) {
-            a.gcost += readlane_f64(cc.x, j);
-            a.optot += readlane_f64(op, j);
-            const double oj = readlane_f64(out, j);
-            const int cj = __builtin_amdgcn_readlane(cls, j);
-            a.co2 += readlane_f64(co2, j);
-            if (cj == 1) a.ig += oj; else if (cj == 2) a.sg += oj; else a.tg += oj;
-          }
-        }
-        a.opcnt += cnt;
-      }
-      for (int base = 0; base < noff_s; base += kWave) {
-        if (base > 0) {
-          const int k = base + lane;
-          const int p = k < noff_s ? sm.opack[k] : 0;
-          const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
-          o_v = offvy[ot * kYears + b]; o_c = offcy[ot * kMults + m];
-        }
-        const double ov = o_v, oc = o_c;
-        const int cnt = noff_s - base < kWave ? noff_s - base : kWave;
-        for (int j = 0; j < cnt; ++j) { a.offs += readlane_f64(ov, j); a.ocost += readlane_f64(oc, j); }
-      }
+      else { a.co2 = ys.co2; a.tg = ys.tg; a.ig = ys.ig; a.sg = ys.sg; }
       EG_T1(0);
     }
     ep.bytes += 2.0 * (double)(n_existing + ep.ngen) * 56.0 + 2.0 * (double)ep.noff * 8.0 + 184.0;
@@ -1035,6 +1073,16 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     }
     if (ep.status != EG_EP_OK) break;
     ep.bytes += 2.0 * (double)(ep.n_act_y + ep.n_def_y);
+    if constexpr (kHelpers > 0) {      // the lists are final for this year: the helper folds next year's starting sums meanwhile
+      if (yi + 1 < kYears) {
+        search_seq += 1; year_seq = search_seq;
+        if (lane == 0) {
+          sm.cmd[search_seq & 1][0] = kCmdYear | (yi + 1) | ((int)((carry_mask >> (yi + 1)) & 1u) << 8);
+          sm.cmd[search_seq & 1][1] = ep.ngen | (ep.noff << 16);
+        }
+        wg_barrier_lds();
+      }
+    }
 
     // ---- yearly metrics (metrics_calculation.rs:32-175) ----
     EG_MARKG(25);
