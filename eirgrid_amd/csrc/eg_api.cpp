@@ -270,6 +270,10 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
       for (int i = 0; i < 14; ++i) b += s->deficit_weights[y * EG_N_DEFICIT + i];
       if (s->count_weights) for (int i = 0; i < EG_N_COUNTS; ++i) { row[snap::kPolCw + i] = s->count_weights[y * EG_N_COUNTS + i]; c2 += row[snap::kPolCw + i]; }
       row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b; row[snap::kPolTotCount] = c2;
+      const HostTables& H = c->tables.H;      // the year's world scalars ride along (eg_internal.h, snap::kPolYear)
+      double* ys = row + snap::kPolYear;
+      ys[0] = H.pre_co2[y]; ys[1] = H.pre_tg[y]; ys[2] = H.pre_ig[y]; ys[3] = H.pre_sg[y]; ys[4] = H.pre_optot[y];
+      ys[5] = H.usage[y]; ys[6] = H.population[y]; ys[7] = H.inflation[y]; ys[8] = H.carbon_price[y]; ys[9] = double(H.pre_opcnt[y]);
     }
   }
   unsigned long long mask[26] = {0}, dmask[26] = {0};

@@ -136,8 +136,12 @@ constexpr size_t kBestCap = 4096;     // best_actions can hold every replay-doub
 // One 128-double block per year carries everything the episode wave loads into LDS at the start of that year:
 //   [0,61) main weights   [61] their table-order sum   [62] sum of the first 14 deficit weights   [63] sum of the count row
 //   [64,79) deficit weights   [79] stalled sampler: sum of the powered weights (written by k_stalled_tables)
-//   [80,101) action-count weights (has_cw)   [101,128) zero
+//   [80,101) action-count weights (has_cw)
+//   [101,111) the world's scalars of that year (copied from the host tables at upload so that they need no LDS table of
+//             their own): existing-plant prefix of CO2 / dispatchable / intermittent / storage output / opinion total,
+//             demand, population, inflation, carbon price, existing-plant count   [111,128) zero
 constexpr int kPolRow = 128, kPolTotMain = 61, kPolTotDeficit = 62, kPolTotCount = 63, kPolDw = 64, kPolScaledTotal = 79, kPolCw = 80;
+constexpr int kPolYear = 101;   // + {0 pre_co2, 1 pre_tg, 2 pre_ig, 3 pre_sg, 4 pre_optot, 5 usage, 6 population, 7 inflation, 8 carbon_price, 9 pre_opcnt}
 constexpr size_t pol = 0;                                                   // f64 [26][128]
 // stalled sampler (sampling.rs:190-220, stall > 500): per year the weights raised to the power in stable descending
 // order and the permutation, evaluated on the device with the shared eg_detpow; valid until the first nudge

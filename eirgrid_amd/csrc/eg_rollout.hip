@@ -49,9 +49,6 @@ struct __align__(16) Smem {
   double type_co2[16];                //                     CO2
   int type_info[16];                  //                     variant | radius class << 4 | reach << 8 | output class << 12
   double acc[8];                      // once-a-year accumulators kept out of registers: total cost / credit / sales, last row
-  double yr[9][EG_YEARS];             // per-year scalars: pre_co2, pre_tg, pre_ig, pre_sg, pre_optot, usage, population,
-                                      // inflation, carbon_price
-  int yr_opcnt[EG_YEARS];
   double pol[snap::kPolRow];          // this year's policy row block (layout: eg_internal.h, namespace snap)
   uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
   uint32_t rng_key[8];                // ChaCha12 key of the episode stream
@@ -71,7 +68,7 @@ struct __align__(16) Smem {
   unsigned long long hdbg[2][4];
 #endif
 };
-static_assert(sizeof(Smem) <= 163840 / 10, "ten episodes per CU");
+static_assert(sizeof(Smem) <= 163840 / 12, "twelve episodes per CU: the same limit as three waves per SIMD");
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
@@ -221,11 +218,6 @@ __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane)
     sm.type_info[lane] = T.variant()[lane] | (rc << 4) | (T.reach()[rc] << 8) | (T.cls()[lane] << 12);
     sm.type_out[lane] = T.out_mw()[lane];
     sm.type_co2[lane] = T.co2_t()[lane];
-  }
-  if (lane < EG_YEARS) {
-    sm.yr[0][lane] = T.pre_co2()[lane]; sm.yr[1][lane] = T.pre_tg()[lane]; sm.yr[2][lane] = T.pre_ig()[lane]; sm.yr[3][lane] = T.pre_sg()[lane];
-    sm.yr[4][lane] = T.pre_optot()[lane]; sm.yr[5][lane] = T.usage()[lane]; sm.yr[6][lane] = T.population()[lane];
-    sm.yr[7][lane] = T.inflation()[lane]; sm.yr[8][lane] = T.carbon_price()[lane]; sm.yr_opcnt[lane] = T.pre_opcnt()[lane];
   }
 }
 
@@ -424,10 +416,19 @@ __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, 
 }
 // starting values of the sums for year yi: zero, or the existing-plant prefix of that year (class sums only when they
 // do not carry over)
-__device__ __forceinline__ YearSums year_sums_init(int yi) {
+// The helper wave asks for NEXT year's values, which are not in LDS yet: it reads the tables; the episode wave reads the
+// copies that came with this year's policy block.
+__device__ __forceinline__ YearSums year_sums_init(const DevTables& T, int yi) {
   YearSums s;
-  s.gcost = 0.0; s.ocost = 0.0; s.offs = 0.0; s.optot = sm.yr[4][yi]; s.opcnt = sm.yr_opcnt[yi];
-  s.co2 = sm.yr[0][yi]; s.tg = sm.yr[1][yi]; s.ig = sm.yr[2][yi]; s.sg = sm.yr[3][yi];
+  s.gcost = 0.0; s.ocost = 0.0; s.offs = 0.0; s.optot = T.pre_optot()[yi]; s.opcnt = T.pre_opcnt()[yi];
+  s.co2 = T.pre_co2()[yi]; s.tg = T.pre_tg()[yi]; s.ig = T.pre_ig()[yi]; s.sg = T.pre_sg()[yi];
+  return s;
+}
+__device__ __forceinline__ YearSums year_sums_init_current() {
+  YearSums s;
+  const double* ys = sm.pol + snap::kPolYear;
+  s.gcost = 0.0; s.ocost = 0.0; s.offs = 0.0; s.optot = ys[4]; s.opcnt = (int)ys[9];
+  s.co2 = ys[0]; s.tg = ys[1]; s.ig = ys[2]; s.sg = ys[3];
   return s;
 }
 
@@ -455,7 +456,7 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     if (c0 & kCmdYear) {      // next year's starting sums (year_fold), while the episode wave closes the current year
       const int yi = c0 & 31, ngen = ngen_s & 0xFFFF, noff = (ngen_s >> 16) & 0xFFFF;
       const bool carry = ((c0 >> 8) & 1) != 0;
-      YearSums ys = year_sums_init(yi);
+      YearSums ys = year_sums_init(T, yi);
       year_fold(T, lane, yi, ngen, noff, carry, year_gather(T, lane, yi, ngen, noff), ys);
       if (lane == 0) {
         sm.ysum[0] = ys.gcost; sm.ysum[1] = ys.optot; sm.ysum[2] = ys.offs; sm.ysum[3] = ys.ocost;
@@ -887,7 +888,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 
     // ---- aggregates at the start of the year (year_gather / year_fold above) ----
     Agg a;
-    a.usage = sm.yr[5][yi];
+    a.usage = sm.pol[snap::kPolYear + 5];
     a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
     {
       EG_MARKG(18);
@@ -898,7 +899,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         ys.gcost = sm.ysum[0]; ys.optot = sm.ysum[1]; ys.offs = sm.ysum[2]; ys.ocost = sm.ysum[3];
         ys.co2 = sm.ysum[4]; ys.tg = sm.ysum[5]; ys.ig = sm.ysum[6]; ys.sg = sm.ysum[7]; ys.opcnt = sm.ysum_opcnt;
       } else {
-        ys = year_sums_init(yi);
+        ys = year_sums_init_current();
         year_fold(T, lane, yi, ngen_s, noff_s, carry, terms, ys);
       }
       a.gcost = ys.gcost; a.optot = ys.optot; a.offs = ys.offs; a.ocost = ys.ocost; a.opcnt = ys.opcnt;
@@ -1088,7 +1089,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     EG_MARKG(25);
     const State s = state_of(a);
     const double gen = (a.tg + a.ig) + a.sg;
-    const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * sm.yr[8][yi];
+    const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * sm.pol[snap::kPolYear + 8];
     const double total_capital = a.gcost + a.ocost;
     const double yearly_capital = yi == 0 ? total_capital : total_capital - (a.gcost_prev + a.ocost_prev);
     double sales = 0.0;
@@ -1105,9 +1106,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     }
     if (S.write_yearly && lane == 0) {   // one lane: 21 adjacent 8-byte stores (merged pairwise)
       double* row = O.yearly(e) + yi * EG_YEARLY_FIELDS;
-      row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = sm.yr[6][yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
+      row[EG_Y_YEAR] = (double)year; row[EG_Y_POP] = sm.pol[snap::kPolYear + 6]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
       row[EG_Y_BALANCE] = s.balance; row[EG_Y_OPINION] = s.opinion; row[EG_Y_YEARLY_CAPITAL] = yearly_capital;
-      row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = sm.yr[7][yi]; row[EG_Y_CO2] = a.co2;
+      row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = sm.pol[snap::kPolYear + 7]; row[EG_Y_CO2] = a.co2;
       row[EG_Y_OFFSET] = a.offs; row[EG_Y_NET_CO2] = s.net; row[EG_Y_YEARLY_CREDIT] = credit; row[EG_Y_TOTAL_CREDIT] = total_credit;
       row[EG_Y_YEARLY_SALES] = sales; row[EG_Y_TOTAL_SALES] = total_sales; row[EG_Y_ACTIVE_GENS] = (double)a.opcnt;
       row[EG_Y_UPGRADE_COSTS] = 0.0; row[EG_Y_CLOSURE_COSTS] = 0.0;   // identically 0 (simulation.rs:41-42)
