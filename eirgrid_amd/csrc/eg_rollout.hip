@@ -1153,7 +1153,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     wg_barrier_lds();
   }
   if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes
-    __threadfence();
+    // The wave re-reads what it stored itself: its stores only have to have left the wave (workgroup-scope release =
+    // s_waitcnt vmcnt(0)); they went through to L2 and nothing of these buffers was ever loaded into this CU's L1.  A
+    // device-scope fence here would write back and invalidate the XCD's L2 once per episode.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wave_sync();
     episode_update_stats(O, S, P, e, lane, stats);
   }
