@@ -48,6 +48,8 @@ struct __align__(16) Smem {
   double type_out[16];                // per generator type: output of an operational new plant
   double type_co2[16];                //                     CO2
   int type_info[16];                  //                     variant | radius class << 4 | reach << 8 | output class << 12
+  double yend[6];                     // last year's end-of-year sums: capital (generators, offsets), CO2, output classes
+  double ystate[4];                   // net CO2 / opinion / balance / cost at the start of the year (success bonus of the repair loop)
   double acc[8];                      // once-a-year accumulators kept out of registers: total cost / credit / sales, last row
   double pol[snap::kPolRow];          // this year's policy row block (layout: eg_internal.h, namespace snap)
   uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
@@ -719,7 +721,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   int run_pos, def_pos, act_pos;      // flat log cursors
   int n_run_y, n_def_y, n_act_y;      // this year's counts
   int status;
-  double bytes;
+  unsigned long long bytes;           // algorithmic bytes of SURVEY §8(d): whole numbers, kept as an integer (scalar registers)
 };
 
 // ---- batch ("reduced") update statistics --------------------------------------------------------------------
@@ -842,7 +844,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   EG_MARKG(16);
 
   Episode ep;
-  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32.0;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull;
   uint8_t* run_log = O.run_log(e);
   uint8_t* def_log = O.def_log(e);
   uint8_t* act_log = O.act_log(e);
@@ -850,9 +852,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   uint16_t* gen_pack = O.gen_pack(e);
   uint16_t* off_pack = O.off_pack(e);
 
-  double gcost_end = 0.0, ocost_end = 0.0;                 // last year's end-of-year capital sums
-  double co2_end = 0.0, tg_end = 0.0, ig_end = 0.0, sg_end = 0.0;   // ... and CO2 / output class sums
-  if (lane < 8) sm.acc[lane] = 0.0;   // [0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row
+  // Wave-uniform doubles that are written once a year and read once a year live in LDS, not in (64-lane) registers:
+  // sm.acc[0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row; sm.yend[0..5] last year's
+  // end-of-year capital sums (generators, offsets) and CO2 / output class sums; sm.ystate the state the year started in
+  if (lane < 8) sm.acc[lane] = 0.0;
+  if (lane < 6) sm.yend[lane] = 0.0;
 
   double np0 = S.pol()[lane], np1 = S.pol()[64 + lane];      // policy row block of year 0; later years are requested a year ahead
   const bool stalled = S.stall > 500u;                        // stalled sampler tables travel the same way
@@ -883,13 +887,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
     Totals tot; tot.main = sm.pol[snap::kPolTotMain]; tot.deficit = sm.pol[snap::kPolTotDeficit]; tot.main_valid = true; tot.deficit_valid = true;
     tot.scaled = sm.pol[snap::kPolScaledTotal]; tot.scaled_valid = true;
-    const double cw_total = sm.pol[snap::kPolTotCount];
     EG_TE(14);
 
     // ---- aggregates at the start of the year (year_gather / year_fold above) ----
     Agg a;
     a.usage = sm.pol[snap::kPolYear + 5];
-    a.gcost_prev = gcost_end; a.ocost_prev = ocost_end;
+    a.gcost_prev = sm.yend[0]; a.ocost_prev = sm.yend[1];
     {
       EG_MARKG(18);
       YearSums ys;
@@ -903,11 +906,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         year_fold(T, lane, yi, ngen_s, noff_s, carry, terms, ys);
       }
       a.gcost = ys.gcost; a.optot = ys.optot; a.offs = ys.offs; a.ocost = ys.ocost; a.opcnt = ys.opcnt;
-      if (carry) { a.co2 = co2_end; a.tg = tg_end; a.ig = ig_end; a.sg = sg_end; }
+      if (carry) { a.co2 = sm.yend[2]; a.tg = sm.yend[3]; a.ig = sm.yend[4]; a.sg = sm.yend[5]; }
       else { a.co2 = ys.co2; a.tg = ys.tg; a.ig = ys.ig; a.sg = ys.sg; }
       EG_T1(0);
     }
-    ep.bytes += 2.0 * (double)(n_existing + ep.ngen) * 56.0 + 2.0 * (double)ep.noff * 8.0 + 184.0;
+    ep.bytes += 2ull * (unsigned long long)(n_existing + ep.ngen) * 56ull + 2ull * (unsigned long long)ep.noff * 8ull + 184ull;
 
     // ---- the year's actions: phase 0 = deficit repair (simulation.rs:137-141, :319-522),
     //      phase 1 = additional actions (simulation.rs:144-198).  One loop so that apply_action is emitted once. ----
@@ -915,7 +918,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
     const State year_start = state_of(a);
     int phase = year_start.balance < 0.0 ? 0 : 1;
-    const State initial = year_start;
+    if (lane == 0) { sm.ystate[0] = year_start.net; sm.ystate[1] = year_start.opinion; sm.ystate[2] = year_start.balance; sm.ystate[3] = year_start.cost; }
     double remaining = -year_start.balance;
     uint32_t attempts = 0, n_add = 0, k_add = 0;
     bool n_add_known = false;
@@ -927,6 +930,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       if (phase == 0) {
         if (!(remaining > 0.0)) {   // deficit closed: success bonus (simulation.rs:491-519), then go on to phase 1
           const State fin = state_of(a);
+          wave_sync();
+          State initial; initial.net = sm.ystate[0]; initial.opinion = sm.ystate[1]; initial.balance = sm.ystate[2]; initial.cost = sm.ystate[3];
           const double success = evaluate_impact(initial, fin);
           if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
             const double factor = 0.1 * success;
@@ -965,7 +970,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
               const double u = rng_f64(rng, lane);
               if (S.has_cw) {
                 const double* cw = SM_CW;
-                const double total = cw_total;   // the count table is never nudged (Q3): its sum is a snapshot constant
+                const double total = sm.pol[snap::kPolTotCount];   // the count table is never nudged (Q3): its sum is a snapshot constant
                 if (total > 0.0) {
                   double v = u * total;
                   n_add = 5u < cap ? 5u : cap;
@@ -998,7 +1003,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       // ---- apply_action (actions.rs:40-204), folded into the aggregates ----
       if (action < kFirstOffset) {
         const int t = action / 3, m = action - 3 * t;
-        ep.bytes += (double)kCells * 8.0 + (double)(n_existing + ep.ngen) * 16.0;
+        ep.bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ep.ngen) * 16ull;
         // terms that depend only on (year, type, multiplier) are requested before the search and land while it runs
         const double2 ccv = *reinterpret_cast<const double2*>(T.cc() + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
         const double cc_prev = yi > 0 ? T.cc()[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
@@ -1073,7 +1078,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       }
     }
     if (ep.status != EG_EP_OK) break;
-    ep.bytes += 2.0 * (double)(ep.n_act_y + ep.n_def_y);
+    ep.bytes += 2ull * (unsigned long long)(ep.n_act_y + ep.n_def_y);
     if constexpr (kHelpers > 0) {      // the lists are final for this year: the helper folds next year's starting sums meanwhile
       if (yi + 1 < kYears) {
         search_seq += 1; year_seq = search_seq;
@@ -1119,8 +1124,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       O.n_def(e)[yi] = ep.n_def_y;
       O.n_act(e)[yi] = ep.n_act_y;
     }
-    gcost_end = a.gcost; ocost_end = a.ocost;
-    co2_end = a.co2; tg_end = a.tg; ig_end = a.ig; sg_end = a.sg;
+    if (lane == 0) { sm.yend[0] = a.gcost; sm.yend[1] = a.ocost; sm.yend[2] = a.co2; sm.yend[3] = a.tg; sm.yend[4] = a.ig; sm.yend[5] = a.sg; }
     EG_T1(4);
   }
 
@@ -1134,7 +1138,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     *O.n_gens(e) = ep.ngen;
     *O.n_offsets(e) = ep.noff;
     *O.n_draws(e) = (unsigned long long)rng.words;
-    *O.bytes_moved(e) = ep.bytes;
+    *O.bytes_moved(e) = (double)ep.bytes;
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
