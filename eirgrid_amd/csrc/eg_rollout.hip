@@ -738,13 +738,16 @@ constexpr double kQ32 = 4294967296.0;
 
 // The policy's scalars as the kernels use them: always read from the snapshot buffer (snap::state), where the host
 // upload or the last on-device update left them.
-__device__ __forceinline__ void load_state(DevSnapshot& S, StatsParams& P) {
+__device__ __forceinline__ void load_stats_params(const DevSnapshot& S, StatsParams& P) {
+  const DevState& st = *S.state();
+  P.best_score = st.p_best_score; P.has_best = st.has_lists; P.threshold = st.p_threshold; P.forced = st.p_forced;
+  P.adaptive_lr = st.p_adaptive_lr; P.stagnation = st.p_stagnation;
+}
+__device__ __forceinline__ void load_state(DevSnapshot& S) {
   const DevState& st = *S.state();
   S.learning_rate = st.learning_rate; S.exploration_rate = st.exploration_rate; S.stall = st.stall; S.has_best = st.has_best;
   S.has_cw = st.has_cw; S.noop_boost = st.noop_boost; S.rel_improvement = st.rel_improvement; S.immediate_weight = st.immediate_weight;
   S.has_best_actions = st.has_lists; S.has_best_deficit = st.has_lists; S.heur_min = st.heur_min; S.heur_max = st.heur_max;
-  P.best_score = st.p_best_score; P.has_best = st.has_lists; P.threshold = st.p_threshold; P.forced = st.p_forced;
-  P.adaptive_lr = st.p_adaptive_lr; P.stagnation = st.p_stagnation;
 }
 
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
@@ -821,8 +824,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave > 0) { helper_loop(T, lane, wave); return; }
   }
-  DevSnapshot S = S_in; StatsParams P;
-  load_state(S, P);
+  DevSnapshot S = S_in;
+  load_state(S);
   // iteration.rs:34-42: which episodes replay the best strategy comes from the caller's mask or, when the policy lives on
   // the device (the host cannot know whether a best strategy exists yet), from a period over the global episode index
   const bool replay = replay_mask != nullptr ? replay_mask[e] != 0
@@ -1163,6 +1166,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wave_sync();
+    StatsParams P;      // only needed here: not held in registers through the episode
+    load_stats_params(S, P);
     episode_update_stats(O, S, P, e, lane, stats);
   }
 }
@@ -1216,7 +1221,7 @@ __global__ void __launch_bounds__(kWave) k_update_stats(DevOut O, DevSnapshot S_
   const uint32_t e = blockIdx.x;
   if (e >= n) return;
   DevSnapshot S = S_in; StatsParams P;
-  load_state(S, P);
+  load_state(S); load_stats_params(S, P);
   episode_update_stats(O, S, P, e, threadIdx.x, stats);
 }
 
