@@ -27,3 +27,11 @@ for k in range(steps):
     print(f"step {k:2d} CUs used {len(counts)}  workgroups per CU: " + " ".join(f"{c}:{int((counts == c).sum())}" for c in sorted(set(counts.tolist()))))
     print(f"step {k:2d} kernel {ms / max(n, 1):.3f} ms  episode cycles mean {tot.mean():8.0f} p50 {srt[B // 2]:8.0f} p99 {srt[int(B * 0.99)]:8.0f} max {srt[-1]:8.0f}  "
           f"max/2.4GHz {srt[-1] / 2.4e6:.3f} ms  placement of slowest {st[int(np.argmax(tot)), 1]:8.0f} gens {res.n_gens[int(np.argmax(tot))]}", flush=True)
+
+names = {0: "year-start aggregates", 1: "placement search", 2: "sampling", 3: "deficit evaluate + nudges", 4: "yearly metrics", 5: "policy block",
+         12: "apply gen", 14: "totals", 15: "initial state", 16: "episode start", 17: "glue year back edge", 18: "glue before aggregates",
+         19: "glue loop top", 20: "glue sampled->search", 21: "glue search->bookkeeping", 22: "glue apply->evaluate", 23: "phase-1 logs", 24: "glue before n_add", 25: "glue exit->metrics"}
+k = int(np.argmax(tot))
+print(f"slowest episode of the last step: {tot[k]:.0f} cycles, gens {res.n_gens[k]}, searches {st[k, 11]:.0f}, chunks {st[k, 8]:.0f}, gen loop {st[k, 9]:.0f}, reduce+merge {st[k, 10]:.0f}, spin {st[k, 6]:.0f}")
+print("  " + "  ".join(f"{n} {100 * st[k, i] / tot[k]:.1f}%" for i, n in names.items()))
+print("mean episode: " + "  ".join(f"{n} {100 * st[:, i].mean() / tot.mean():.1f}%" for i, n in names.items()))
