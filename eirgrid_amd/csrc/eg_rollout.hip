@@ -262,6 +262,41 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return __hiloint2double((int)mh, (int)ml);
 }
 
+// Inclusive prefix sum over the 64 lanes (DPP: four row shifts, two row broadcasts; a lane without a source adds 0.0).
+__device__ __forceinline__ double wave_prefix_sum_f64(double x) {
+#define EG_DPP_ADD_STEP(ctrl, row_mask, bank_mask)                                                                  \
+  {                                                                                                                 \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, row_mask, bank_mask, false);             \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, row_mask, bank_mask, false);             \
+    x = x + __hiloint2double(hi, lo);                                                                               \
+  }
+  EG_DPP_ADD_STEP(0x111, 0xf, 0xf)   // row_shr:1
+  EG_DPP_ADD_STEP(0x112, 0xf, 0xf)   // row_shr:2
+  EG_DPP_ADD_STEP(0x114, 0xf, 0xf)   // row_shr:4
+  EG_DPP_ADD_STEP(0x118, 0xf, 0xf)   // row_shr:8
+  EG_DPP_ADD_STEP(0x142, 0xa, 0xf)   // row_bcast:15 -> rows 1, 3
+  EG_DPP_ADD_STEP(0x143, 0xc, 0xf)   // row_bcast:31 -> rows 2, 3
+#undef EG_DPP_ADD_STEP
+  return x;
+}
+
+// The weighted walk of the samplers (sampling.rs:223-233, :362-370, :406-416): v = V, then v -= table[a] in table order;
+// the pick is the number of entries after which v was still positive (weights are not negative, so v never grows).
+// Each subtraction rounds, so the walk itself is sequential — but its OUTCOME only depends on the signs of the v_a, and
+// v_a differs from V - (w_0 + ... + w_a) evaluated in any other order by less than 2^-46 * total (61 roundings of values
+// below `total` on one side, a 6-level tree and one subtraction on the other).  So: prefix sums in parallel, and if
+// every V - P_a is further than 2^-40 * total from zero the signs — hence the pick — are those of the sequential walk.
+// Otherwise (a draw within 1e-12 of a boundary) the sequential walk decides.
+__device__ __forceinline__ int weighted_pick(const double* table, int n, double V, double total, int lane) {
+  const double w = lane < n ? table[lane] : 0.0;
+  const double d = V - wave_prefix_sum_f64(w);
+  const unsigned long long valid = (1ull << n) - 1ull;      // n < 64
+  if ((__ballot(dabs(d) <= total * 0x1p-40) & valid) == 0ull) return __popcll(__ballot(d > 0.0) & valid);
+  int pick = 0; double v = V;
+  for (int a = 0; a < n; ++a) { v -= table[a]; pick += v > 0.0 ? 1 : 0; }
+  return pick;
+}
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 // byte offset into the 13x13 factor table of a radius class: (min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)) * 8,
 // packed 16-bit arithmetic and one dot product
@@ -672,30 +707,12 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
       for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
       tot.scaled = total_scaled; tot.scaled_valid = true;
     }
-    double v = rng_f64(r, lane) * tot.scaled;
-    int idx = 0;                                  // the powered weights are > 0: count the entries still above zero
-    for (int i0 = 0; i0 < EG_N_ACTIONS; i0 += 8) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u;
-        if (i < EG_N_ACTIONS) { v -= sm.scaled[i]; idx += v > 0.0 ? 1 : 0; }
-      }
-      if (!(v > 0.0)) break;
-    }
+    const int idx = weighted_pick(sm.scaled, EG_N_ACTIONS, rng_f64(r, lane) * tot.scaled, tot.scaled, lane);
     return sm.ydef[128 + (idx < EG_N_ACTIONS ? idx : 0)];
   }
-  double v = rng_f64(r, lane) * total;
   // Every weight is >= MIN_WEIGHT > 0, so the running value only decreases: the entry at which it first reaches <= 0 is
-  // the number of entries after which it was still positive.  Eight entries per trip, branch-free inside.
-  int pick = 0;
-  for (int a0 = 0; a0 < EG_N_ACTIONS; a0 += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int a = a0 + u;
-      if (a < EG_N_ACTIONS) { v -= SM_W[a]; pick += v > 0.0 ? 1 : 0; }
-    }
-    if (!(v > 0.0)) break;
-  }
+  // the number of entries after which it was still positive.
+  const int pick = weighted_pick(SM_W, EG_N_ACTIONS, rng_f64(r, lane) * total, total, lane);
   return pick < EG_N_ACTIONS ? pick : 3 * kPeaker;
 }
 __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:315-377
@@ -709,10 +726,7 @@ __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot
   }
   const double total = tot.deficit;
   if (total <= 0.0) return 3 * kPeaker;
-  double v = rng_f64(r, lane) * total;
-  int pick = 0;
-#pragma unroll 7
-  for (int i = 0; i < 14; ++i) { v -= SM_DW[i]; pick += v > 0.0 ? 1 : 0; }
+  const int pick = weighted_pick(SM_DW, 14, rng_f64(r, lane) * total, total, lane);
   return pick < 14 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
 }
 
@@ -974,11 +988,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
               if (S.has_cw) {
                 const double* cw = SM_CW;
                 const double total = sm.pol[snap::kPolTotCount];   // the count table is never nudged (Q3): its sum is a snapshot constant
-                if (total > 0.0) {
-                  double v = u * total;
-                  n_add = 5u < cap ? 5u : cap;
-#pragma unroll 3
-                  for (uint32_t c = 0; c < (uint32_t)EG_N_COUNTS; ++c) { v -= cw[c]; if (v <= 0.0) { n_add = c < cap ? c : cap; break; } }
+                if (total > 0.0) {      // the first count at which the walk reaches <= 0; none: 5 (sampling.rs:406-421)
+                  const uint32_t c = (uint32_t)weighted_pick(cw, EG_N_COUNTS, u * total, total, lane);
+                  n_add = c < (uint32_t)EG_N_COUNTS ? (c < cap ? c : cap) : (5u < cap ? 5u : cap);
                 }
               } else {   // heuristic branch; min/max actions were evaluated on the host (sampling.rs:425-427)
                 const uint32_t hi = S.heur_max < cap ? S.heur_max : cap;
