@@ -17,6 +17,7 @@
 //   metrics        analysis/metrics_calculation.rs:7-175, ai/metrics/scoring.rs:46-85
 //   RNG            rand 0.8.5 StdRng = ChaCha12 behind rand_core BlockRng (Cargo.lock:763-785)
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <hip/hip_ext.h>
 
 #include "eg_internal.h"
@@ -91,9 +92,8 @@ struct Rng {      // register part of the stream state; key / counter / buffer l
   int index;
   unsigned int words;
 };
-struct Totals {   // sums of the weight rows in table order (sampling.rs:182, :352-355); recomputed only after a nudge
-  double main, deficit, scaled;
-  bool main_valid, deficit_valid, scaled_valid;   // scaled_*: the stalled sampler's sorted / powered table in LDS
+struct Totals {   // (the sums of the rows themselves are taken inside weighted_pick)
+  bool scaled_valid;   // the stalled sampler's sorted / powered table in LDS matches the weight row
 };
 
 struct Agg {   // aggregates of the map at the current point of the year (map_handler.rs:819-965)
@@ -280,19 +280,28 @@ __device__ __forceinline__ double wave_prefix_sum_f64(double x) {
   return x;
 }
 
-// The weighted walk of the samplers (sampling.rs:223-233, :362-370, :406-416): v = V, then v -= table[a] in table order;
-// the pick is the number of entries after which v was still positive (weights are not negative, so v never grows).
-// Each subtraction rounds, so the walk itself is sequential — but its OUTCOME only depends on the signs of the v_a, and
-// v_a differs from V - (w_0 + ... + w_a) evaluated in any other order by less than 2^-46 * total (61 roundings of values
-// below `total` on one side, a 6-level tree and one subtraction on the other).  So: prefix sums in parallel, and if
-// every V - P_a is further than 2^-40 * total from zero the signs — hence the pick — are those of the sequential walk.
-// Otherwise (a draw within 1e-12 of a boundary) the sequential walk decides.
-__device__ __forceinline__ int weighted_pick(const double* table, int n, double V, double total, int lane) {
+// The weighted pick of the samplers (sampling.rs:182-233, :352-370, :406-416): total = sum of the table in table order,
+// v = u * total, then v -= table[a] in table order; the pick is the number of entries after which v was still positive
+// (weights are not negative, so v never grows).  Every addition and subtraction rounds, so sum and walk are sequential
+// chains — but the OUTCOME only depends on the signs of the v_a, and v_a differs from u * T - P_a, with the prefix sums
+// P_a and their last value T evaluated in any other order, by less than 2^-45 * total (61 roundings of values below
+// `total` in the sequential sum, 61 in the walk, a 6-level tree on the other side, one multiplication and one
+// subtraction each).  So: prefix sums in parallel, and if every u * T - P_a is further than 2^-40 * T from zero the signs
+// — hence the pick — are those of the sequential sum-and-walk.  Otherwise (a draw within 1e-12 of a boundary) the
+// sequential chains decide.  tests/test_weighted_pick.py checks the rule on the CPU.
+// Not inlined (four call sites; inlined, the rarely-run sequential part costs the episode loop its registers).  The table
+// is given by its byte offset inside the workgroup's LDS block so that it is read with LDS instructions.
+__device__ __noinline__ int weighted_pick(int table_offset, int n, double u, int lane) {
+  const double* table = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table_offset);
   const double w = lane < n ? table[lane] : 0.0;
-  const double d = V - wave_prefix_sum_f64(w);
+  const double P = wave_prefix_sum_f64(w);
+  const double T = readlane_f64(P, kWave - 1);             // lanes >= n added 0.0
+  const double d = u * T - P;
   const unsigned long long valid = (1ull << n) - 1ull;      // n < 64
-  if ((__ballot(dabs(d) <= total * 0x1p-40) & valid) == 0ull) return __popcll(__ballot(d > 0.0) & valid);
-  int pick = 0; double v = V;
+  if ((__ballot(dabs(d) <= T * 0x1p-40) & valid) == 0ull) return __popcll(__ballot(d > 0.0) & valid);
+  double total = 0.0;
+  for (int a = 0; a < n; ++a) total += table[a];
+  int pick = 0; double v = u * total;
   for (int a = 0; a < n; ++a) { v -= table[a]; pick += v > 0.0 ? 1 : 0; }
   return pick;
 }
@@ -680,14 +689,6 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
   const double eps = S.stall > 100u ? S.exploration_rate * (1.0 / (1.0 + 0.01 * (double)S.stall)) : S.exploration_rate;
   const bool explore = rng_f64(r, lane) < eps;
   if (explore) return (int)rng_range64(r, lane, (unsigned long long)EG_N_ACTIONS);
-  if (!tot.main_valid) {
-    double t = 0.0;
-#pragma unroll 4
-    for (int a = 0; a < EG_N_ACTIONS; ++a) t += SM_W[a];
-    tot.main = t; tot.main_valid = true;
-  }
-  const double total = tot.main;
-  if (total <= 0.0) return 3 * kPeaker;
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
     if (!tot.scaled_valid) {   // the row was nudged this year: rebuild the table (otherwise it is the host-built one)
       const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
@@ -702,31 +703,20 @@ __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot,
         sm.ydef[128 + rank] = (uint8_t)lane;
       }
       wave_sync();
-      double total_scaled = 0.0;
-#pragma unroll 4
-      for (int i = 0; i < EG_N_ACTIONS; ++i) total_scaled += sm.scaled[i];
-      tot.scaled = total_scaled; tot.scaled_valid = true;
+      tot.scaled_valid = true;
     }
-    const int idx = weighted_pick(sm.scaled, EG_N_ACTIONS, rng_f64(r, lane) * tot.scaled, tot.scaled, lane);
+    const int idx = weighted_pick((int)offsetof(Smem, scaled), EG_N_ACTIONS, rng_f64(r, lane), lane);
     return sm.ydef[128 + (idx < EG_N_ACTIONS ? idx : 0)];
   }
   // Every weight is >= MIN_WEIGHT > 0, so the running value only decreases: the entry at which it first reaches <= 0 is
   // the number of entries after which it was still positive.
-  const int pick = weighted_pick(SM_W, EG_N_ACTIONS, rng_f64(r, lane) * total, total, lane);
+  const int pick = weighted_pick((int)offsetof(Smem, pol), EG_N_ACTIONS, rng_f64(r, lane), lane);
   return pick < EG_N_ACTIONS ? pick : 3 * kPeaker;
 }
 __device__ int sample_deficit_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:315-377
   const bool explore = rng_f64(r, lane) < S.exploration_rate;
   if (explore) return 3 * c_deficit_type[(int)rng_range64(r, lane, 14ull)];
-  if (!tot.deficit_valid) {
-    double t = 0.0;
-#pragma unroll 7
-    for (int i = 0; i < 14; ++i) t += SM_DW[i];
-    tot.deficit = t; tot.deficit_valid = true;
-  }
-  const double total = tot.deficit;
-  if (total <= 0.0) return 3 * kPeaker;
-  const int pick = weighted_pick(SM_DW, 14, rng_f64(r, lane) * total, total, lane);
+  const int pick = weighted_pick((int)(offsetof(Smem, pol) + 8 * snap::kPolDw), 14, rng_f64(r, lane), lane);
   return pick < 14 ? 3 * c_deficit_type[pick] : 3 * kPeaker;
 }
 
@@ -902,8 +892,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     EG_T1(5);
     }
     ep.n_run_y = 0; ep.n_def_y = 0; ep.n_act_y = 0;
-    Totals tot; tot.main = sm.pol[snap::kPolTotMain]; tot.deficit = sm.pol[snap::kPolTotDeficit]; tot.main_valid = true; tot.deficit_valid = true;
-    tot.scaled = sm.pol[snap::kPolScaledTotal]; tot.scaled_valid = true;
+    Totals tot; tot.scaled_valid = true;
     EG_TE(14);
 
     // ---- aggregates at the start of the year (year_gather / year_fold above) ----
@@ -954,7 +943,6 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
             const double factor = 0.1 * success;
             wave_sync();
             for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, lane, sm.ydef[i], factor);
-            tot.deficit_valid = false;
           }
           phase = 1;
           continue;
@@ -986,10 +974,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
             if (cap > 0u) {
               const double u = rng_f64(rng, lane);
               if (S.has_cw) {
-                const double* cw = SM_CW;
                 const double total = sm.pol[snap::kPolTotCount];   // the count table is never nudged (Q3): its sum is a snapshot constant
                 if (total > 0.0) {      // the first count at which the walk reaches <= 0; none: 5 (sampling.rs:406-421)
-                  const uint32_t c = (uint32_t)weighted_pick(cw, EG_N_COUNTS, u * total, total, lane);
+                  const uint32_t c = (uint32_t)weighted_pick((int)(offsetof(Smem, pol) + 8 * snap::kPolCw), EG_N_COUNTS, u, lane);
                   n_add = c < (uint32_t)EG_N_COUNTS ? (c < cap ? c : cap) : (5u < cap ? 5u : cap);
                 }
               } else {   // heuristic branch; min/max actions were evaluated on the host (sampling.rs:425-427)
@@ -1082,7 +1069,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
         update_deficit_weights(S, lane, action, combined);
         update_weights(S, lane, action, overall * 0.5);
-        tot.main_valid = false; tot.deficit_valid = false; tot.scaled_valid = false;
+        tot.scaled_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
         EG_T1(3);
       } else {            // simulation.rs:193-197

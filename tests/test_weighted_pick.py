@@ -1,7 +1,8 @@
-"""The device samplers pick by parallel prefix sums when that is provably the sequential walk's answer
+"""The device samplers pick by parallel prefix sums when that is provably the sequential sum-and-walk's answer
 (eg_rollout.hip: weighted_pick).  This checks the bound the kernel relies on, on the CPU, with the same rule:
-if every V - P_a (P_a = prefix sums in tree order) is further than 2^-40 * total from zero, the number of positive
-V - P_a equals the number of positive values of the sequential float walk v -= w_a."""
+with P_a = prefix sums in tree order and T their last value, if every u * T - P_a is further than 2^-40 * T from zero, the
+number of positive u * T - P_a equals the number of positive values of the reference's chains: total = w_0 + w_1 + ...
+in order, v = u * total, v -= w_a in order."""
 import numpy as np
 
 
@@ -24,8 +25,11 @@ def _tree_prefix(w):
     return y
 
 
-def _sequential_pick(w, V):
-    v = V; pick = 0
+def _sequential_pick(w, u):
+    total = 0.0
+    for x in w:
+        total += x
+    v = u * total; pick = 0
     for a in range(len(w)):
         v = v - w[a]; pick += v > 0.0
     return pick
@@ -42,20 +46,22 @@ def test_parallel_pick_agrees_whenever_it_is_trusted():
             total += x
         mode = trial % 4
         if mode == 0:
-            V = rng.uniform() * total
+            u = rng.uniform()
         else:
             k = int(rng.integers(0, n)); b = 0.0
             for x in w[:k + 1]:
                 b += x
             if mode == 1:         # on or within a few ulps of a boundary of the sequential walk: must be left to it
-                V = float(np.nextafter(b, b + rng.choice([-1.0, 1.0]) * rng.integers(0, 4)))
+                u = float(np.nextafter(b / total, rng.choice([0.0, 1.0])) if rng.integers(0, 2) else b / total)
             else:                 # just outside the tolerance: the closest the parallel rule is ever trusted
-                V = b + rng.choice([-1.0, 1.0]) * total * 2.0 ** -40 * (1.0 + 3.0 * rng.uniform())
-            V = min(max(V, 0.0), float(np.nextafter(total, 0.0)))
-        d = V - _tree_prefix(w)[:n]
-        if (np.abs(d) <= total * 2.0 ** -40).any():
-            ambiguous += 1        # the kernel walks sequentially here
+                u = b / total + rng.choice([-1.0, 1.0]) * 2.0 ** -40 * (1.0 + 3.0 * rng.uniform())
+            u = min(max(u, 0.0), float(np.nextafter(1.0, 0.0)))
+        P = _tree_prefix(w)
+        T = P[63]
+        d = u * T - P[:n]
+        if (np.abs(d) <= T * 2.0 ** -40).any():
+            ambiguous += 1        # the kernel evaluates the sequential chains here
             continue
         trusted += 1
-        assert int((d > 0).sum()) == _sequential_pick(w, V), (trial, n, V)
+        assert int((d > 0).sum()) == _sequential_pick(w, u), (trial, n, u)
     assert trusted > 2500 and ambiguous > 900
