@@ -1003,6 +1003,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       }
 
       // ---- apply_action (actions.rs:40-204), folded into the aggregates ----
+      // (the action index is the same in every lane; saying so moves the index arithmetic below to the scalar unit)
+      action = __builtin_amdgcn_readfirstlane(action);
       if (action < kFirstOffset) {
         const int t = action / 3, m = action - 3 * t;
         ep.bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ep.ngen) * 16ull;
@@ -1013,11 +1015,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
-        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq, stamps);
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq, stamps));
         stamps[11] += 1;
 #else
         double m03v = 0.0;
-        const int cell = place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq);
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq));
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
