@@ -540,7 +540,7 @@ template <int kHelpers>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
                                             double* best_m03, PrefixCache& cache0, uint32_t* seq = nullptr,
                                             unsigned long long* stamps = nullptr) {
-  const int info = sm.type_info[type];
+  const int info = __builtin_amdgcn_readfirstlane(sm.type_info[type]);      // uniform: list address arithmetic on the scalar unit
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
   const double* dr = sm.dr + rc * 169;
@@ -951,7 +951,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         EG_MARKG(19);
         if (attempts < 5u) {
           if (replay) {   // sampling.rs:242-313
-            const int lo = S.bestd_off()[yi], n = S.bestd_off()[yi + 1] - lo;
+            const int lo = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi]), n = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi + 1]) - lo;
             if (S.has_best_deficit && replay_def_idx < n) { action = S.bestd_actions()[lo + replay_def_idx]; replay_def_idx += 1; }
             else action = smart_deficit_fallback(rng, lane);
             if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; break; }
@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         k_add += 1;
         EG_MARKG(19);
         if (replay) {   // sampling.rs:78-145
-          const int lo = S.best_off()[yi], n = S.best_off()[yi + 1] - lo;
+          const int lo = __builtin_amdgcn_readfirstlane(S.best_off()[yi]), n = __builtin_amdgcn_readfirstlane(S.best_off()[yi + 1]) - lo;
           if (S.has_best_actions && replay_idx < n) { action = S.best_actions()[lo + replay_idx]; replay_idx += 1; }
           else action = smart_fallback(rng, lane, year);
           if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
