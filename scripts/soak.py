@@ -1,0 +1,68 @@
+"""Soak test on the GPU box (not part of pytest: minutes, not seconds).
+  python scripts/soak.py [trials]
+Every trial draws a random policy (perturbed tables, stall, rates, random best lists), runs 1,536 episodes through BOTH
+kernels (helper-wave and single-wave) and demands identical bytes, checks 48 random episodes against the tabled CPU
+oracle bit for bit, and then takes 6 training steps on the device and on the host from that policy and demands identical
+policies.  Exit code 0 = everything matched."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from eirgrid_amd import synthetic_world
+from eirgrid_amd.engine import ActionWeights, Engine, HostTables
+from oracle import api as O
+from tests.helpers import assert_episode_equal, oracle_weights_like
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+world = synthetic_world()
+engines = {}
+for mode in ("0", "all"):
+    os.environ["EIRGRID_HELPER_WAVES"] = mode
+    engines[mode] = Engine(world, device=0)
+del os.environ["EIRGRID_HELPER_WAVES"]
+dev = Engine(world, device=0)
+tb = O.OracleTables(HostTables(world), len(world.existing_x))
+rng = np.random.default_rng(int(time.time()) if len(sys.argv) > 2 else 20261004)
+t0 = time.time()
+for trial in range(trials):
+    pol = ActionWeights()
+    run = [rng.integers(0, 61, int(rng.choice([0, 0, 1, 2, 5, 9]))).tolist() for _ in range(26)]
+    dfl = [(3 * rng.choice([8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14], int(rng.choice([0, 1, 2, 3])))).tolist() for _ in range(26)]
+    nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
+    pol.apply_episode([float(rng.choice([-5e4, 3e5])), 0.7, float(rng.choice([4e10, 9e11])), 1.0], nr,
+                      np.array([a for l in run for a in l], np.uint8), nd, np.array([a for l in dfl for a in l], np.uint8))
+    w, dw, cw = pol.tables()
+    pol.set_tables(np.clip(w * 10 ** rng.uniform(-1.5, 1.0, w.shape), 1e-4, 0.999), np.clip(dw * 10 ** rng.uniform(-1.5, 1.0, dw.shape), 1e-4, 0.999),
+                   cw * rng.uniform(0.2, 3.0, cw.shape))
+    pol.set("iterations_without_improvement", int(rng.choice([0, 50, 150, 480, 520, 1400, 4000])))
+    pol.set("learning_rate", float(rng.uniform(0.05, 0.5))); pol.set("exploration_rate", float(rng.uniform(0.0, 0.9)))
+    if trial % 3 == 2:
+        pol.set("has_count_weights", 0)
+    n = 1536; seed = int(rng.integers(1, 2**40)); first = int(rng.integers(0, 2**20))
+    mask = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    a = engines["0"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+    b = engines["all"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+    for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
+        assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (trial, name)
+    ok = np.flatnonzero(a.status == 0)
+    for e in rng.choice(ok, min(48, len(ok)), replace=False):
+        st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), seed + first + int(e), replay=bool(mask[e]))
+        assert_episode_equal(b, int(e), ref, f"soak trial {trial}")
+    # six training steps: device-resident vs host update
+    host = ActionWeights(); host.set_tables(*pol.tables())
+    for name in ("iterations_without_improvement", "learning_rate", "exploration_rate", "has_count_weights"):
+        host.set(name, pol.get(name))
+    devp = ActionWeights(); devp.set_tables(*host.tables())
+    for name in ("iterations_without_improvement", "learning_rate", "exploration_rate", "has_count_weights"):
+        devp.set(name, host.get(name))
+    dev.push(devp)
+    for step in range(6):
+        f = first + step * 256
+        m = ((np.arange(f, f + 256) % 3) == 0).astype(np.uint8) if host.get("has_best_actions") == 1 else None
+        engines["0"].train_step(host, seed, f, 256, m, noise_seed=seed + step)
+        dev.device_step(seed, f, 256, 3, seed + step)
+    dev.pull(devp)
+    for x, y in zip(host.tables(), devp.tables()):
+        assert x.tobytes() == y.tobytes(), (trial, "device vs host policy")
+    assert host.lists(0) == devp.lists(0) and host.get("iterations_without_improvement") == devp.get("iterations_without_improvement")
+    print(f"trial {trial:3d} ok  ({time.time() - t0:.0f} s; failed episodes in batch: {int((a.status != 0).sum())})", flush=True)
+print("soak: all", trials, "trials matched")
