@@ -213,8 +213,11 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 }
 
 // small per-type / per-class tables -> LDS (one dependent LDS read instead of chains of L2 round trips)
-__device__ __forceinline__ void load_static_tables(const DevTables& T, int lane) {
+__device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) {
   for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr()[i];
+}
+__device__ __forceinline__ void load_static_tables(const DevTables& T, int lane, bool with_factors) {
+  if (with_factors) load_factor_table(T, lane);
   if (lane < kTypes) {
     const int rc = T.rclass()[lane];
     sm.type_info[lane] = T.variant()[lane] | (rc << 4) | (T.reach()[rc] << 8) | (T.cls()[lane] << 12);
@@ -826,7 +829,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave > 0) { helper_loop(T, lane, wave); return; }
+    // (the helper also brings the 8 KB factor table into LDS: it has nothing else to do until the first search, and the
+    //  barrier of that search orders its LDS writes before anybody's reads)
+    if (wave > 0) { load_factor_table(T, lane); helper_loop(T, lane, wave); return; }
   }
   DevSnapshot S = S_in;
   load_state(S);
@@ -841,7 +846,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   unsigned long long last_ = t_begin;
 #endif
 
-  load_static_tables(T, lane);
+  load_static_tables(T, lane, kHelpers == 0);
   // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
   const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
                                                  T.pre_tg()[lane] == T.pre_tg()[lane - 1] && T.pre_ig()[lane] == T.pre_ig()[lane - 1] &&
@@ -1178,7 +1183,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
                                                  int n_extra, int32_t* out_cell, double* out_score) {
   const int lane = threadIdx.x;
   for (int g = lane; g < n_extra; g += kWave) sm.gcell[g] = cells[g];
-  load_static_tables(T, lane);
+  load_static_tables(T, lane, true);
   __syncthreads();
   double score = 0.0;
   PrefixCache pc0 = {0.0, -1, 0};
