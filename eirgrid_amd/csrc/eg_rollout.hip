@@ -1,11 +1,15 @@
 // eg_rollout.hip — CDNA4 (gfx950) kernels of the rollout engine.
 //
-// One wavefront (64 lanes, one workgroup) runs one 2025–2050 episode from start to finish; a batch is a grid of
-// episodes.  Control flow of an episode is wave-uniform (every lane carries the same scalar state), the lanes
-// fan out over (a) the 51x51 candidate grid of the placement search, which lives in LDS, (b) the penalty box of
-// each generator, (c) the per-year table rows and the weight-table updates.  All sums and products are folded
-// in the reference's list order and every transcendental is a host-built table (eg_tables.cpp), so device code
-// is + - * / compare only and reproduces the CPU oracle bit for bit.  Build: -ffp-contract=off (no FMA).
+// One wavefront runs one 2025–2050 episode from start to finish; a batch is a grid of episodes, one workgroup each
+// (k_rollout<0>: the episode wave alone; k_rollout<1>, small batches: plus a helper wave, see helper_loop).  Control
+// flow of an episode is wave-uniform (every lane carries the same scalar state); the lanes fan out over the 64
+// candidates of a chunk of the placement search, the per-generator / per-offset gathers at the start of a year, the
+// weight rows (nudges, prefix scans of the samplers) and the ChaCha blocks.  Sums and products that end up in an output
+// are folded in the reference's list order and every transcendental is a host-built table (eg_tables.cpp), so device
+// code is + - * / compare only and reproduces the CPU oracle bit for bit; chains that only feed a decision (the samplers'
+// sum-and-walk) are replaced by a parallel form where that provably gives the same decision (weighted_pick).
+// Build: -ffp-contract=off (no FMA).  Further kernels: k_apply_update (the batch update, on the device),
+// k_stalled_tables, k_pick_best, k_update_stats, k_place.
 //
 // Reference (paths relative to /root/reference/aiSimulator/src/):
 //   episode        core/simulation.rs:22-317, core/iteration.rs:57-74
