@@ -291,3 +291,40 @@ def test_device_update_from_two_rank_packets(engine, world):
             assert a.get("iteration_count") == b.get("iteration_count") == (step + 1) * 2 * n
     finally:
         dev.close()
+
+
+def test_device_resident_training_survives_pull_and_push(engine, world, tmp_path):
+    """Checkpoint / resume of the device-resident loop: 12 steps in one go == 6 steps, eg_policy_pull, a JSON round trip
+    is NOT taken (count weights would be dropped, as in the reference) but a fresh engine and eg_policy_push, 6 more."""
+    from eirgrid_amd.engine import Engine
+    n, period = 128, 5
+    a = ActionWeights(); engine.push(a)
+    for step in range(12):
+        engine.device_step(97, step * n, n, period, 300 + step)
+    engine.pull(a)
+    b = ActionWeights(); engine.push(b)
+    for step in range(6):
+        engine.device_step(97, step * n, n, period, 300 + step)
+    engine.pull(b)
+    other = Engine(world, device=0)
+    try:
+        other.push(b)
+        for step in range(6, 12):
+            other.device_step(97, step * n, n, period, 300 + step)
+        other.pull(b)
+    finally:
+        other.close()
+    for x, y in zip(a.tables(), b.tables()):
+        assert x.tobytes() == y.tobytes()
+    assert a.lists(0) == b.lists(0) and a.lists(1) == b.lists(1)
+    for name in ("iterations_without_improvement", "iteration_count", "has_best", "best_cost", "improvement_history_len"):
+        assert a.get(name) == b.get(name), name
+    # and the checkpoint written from the pulled policy is the one the host-driven loop writes
+    pa, pb = tmp_path / "a.json", tmp_path / "b.json"
+    a.save_to_file(str(pa)); b.save_to_file(str(pb))
+    import json
+    ja, jb = json.load(open(pa)), json.load(open(pb))
+    for j in (ja, jb):      # timestamps differ
+        for rec in j.get("improvement_history") or []:
+            rec.pop("timestamp", None)
+    assert ja == jb
