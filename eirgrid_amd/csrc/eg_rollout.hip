@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         } else action = 3 * kBattery;   // simulation.rs:369-376
         EG_T1(2);
         if (action >= kFirstOffset) continue;   // only AddGenerator actions are applied in the repair loop (:398)
-        cur = state_of(a);
+        // (`cur`, the state before this action, is the state after the previous one: nothing changes the map in between)
       } else {
         if (!n_add_known) {   // simulation.rs:144-187
           n_add_known = true;
@@ -1072,16 +1072,28 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         ep.def_pos += 1; ep.n_def_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
         EG_MARKG(22);
         const State nxt = state_of(a);
-        const double overall = evaluate_impact(cur, nxt);
-        const double em = nxt.net < cur.net ? (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0) : 0.0;
-        double ci = 0.0;
-        if (nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; ci = -cost_change / dmax(dabs(cur.cost), 1.0); }
+        // evaluate_action_impact (scoring.rs:46-85) and the emission / cost terms of simulation.rs:420-452 divide the same
+        // differences by the same denominators: each quotient is formed once
+        const bool net_positive = cur.net > 0.0;
+        double q_net = 0.0, q_cost = 0.0;
+        if (net_positive || nxt.net < cur.net) q_net = (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0);
+        if (!net_positive || nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; q_cost = -cost_change / dmax(dabs(cur.cost), 1.0); }
+        double overall;
+        if (net_positive) overall = q_net;
+        else {
+          const double opinion_improvement = (nxt.opinion - cur.opinion) / dmax(dabs(cur.opinion), 1.0);
+          const double cost_weight = cur.cost > kMaxCost * 8.0 ? 0.8 : 0.5;
+          overall = q_cost * cost_weight + opinion_improvement * (1.0 - cost_weight);
+        }
+        const double em = nxt.net < cur.net ? q_net : 0.0;
+        const double ci = nxt.net < 1000.0 ? q_cost : 0.0;
         const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
         update_deficit_weights(S, lane, action, combined);
         update_weights(S, lane, action, overall * 0.5);
         tot.scaled_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
+        cur = nxt;
         EG_T1(3);
       } else {            // simulation.rs:193-197
         if (ep.act_pos >= EG_ACT_CAP || ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
