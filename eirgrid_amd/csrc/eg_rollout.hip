@@ -944,7 +944,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       int action;
       if (phase == 0) {
         if (!(remaining > 0.0)) {   // deficit closed: success bonus (simulation.rs:491-519), then go on to phase 1
-          const State fin = state_of(a);
+          const State fin = cur;      // the state after the last repair action (the map has not changed since)
           wave_sync();
           State initial; initial.net = sm.ystate[0]; initial.opinion = sm.ystate[1]; initial.balance = sm.ystate[2]; initial.cost = sm.ystate[3];
           const double success = evaluate_impact(initial, fin);
