@@ -314,15 +314,16 @@ __device__ __noinline__ int weighted_pick(int table_offset, int n, double u, int
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
-// byte offset into the 13x13 factor table of a radius class: (min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)) * 8,
-// packed 16-bit arithmetic and one dot product
-__device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed) {
+// byte offset of a factor inside the workgroup's LDS block: base (the 13x13 table of the radius class) +
+// (min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)) * 8 — packed 16-bit arithmetic and one dot product that accumulates onto
+// the base
+__device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed, int base) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
   short2v d = cpk - g;
   const short2v cap = {12, 12}, stride = {13 * 8, 8};
   d = __builtin_elementwise_max(d, g - cpk);
   d = __builtin_elementwise_min(d, cap);
-  return __builtin_amdgcn_sdot2(d, stride, 0, false);
+  return __builtin_amdgcn_sdot2(d, stride, base, false);
 }
 
 // A search multiplies te by the factor of every generator, in list order.  Searches of the same (year, variant) revisit
@@ -336,7 +337,7 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
-  const char* drb = reinterpret_cast<const char*>(dr);
+  const int dr_off = (int)(reinterpret_cast<const char*>(dr) - reinterpret_cast<const char*>(&sm));   // table base inside the LDS block
   for (int gb = k0; gb < ngen_s; gb += kWave) {                   // generators in list order
     // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
     const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
@@ -347,7 +348,7 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
     // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
     // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
     // current four are multiplied in list order (only the multiplies form a chain).
-#define EG_FACTOR(j) (*reinterpret_cast<const double*>(drb + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)))))
+#define EG_FACTOR(j) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)), dr_off)))
     double f0 = EG_FACTOR(0), f1 = EG_FACTOR(1), f2 = EG_FACTOR(2), f3 = EG_FACTOR(3);
     for (int j = 4; j < cnt; j += 4) {
       const double g0 = EG_FACTOR(j), g1 = EG_FACTOR(j + 1), g2 = EG_FACTOR(j + 2), g3 = EG_FACTOR(j + 3);
