@@ -635,22 +635,6 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
-__device__ void update_weights(const DevSnapshot& S, int lane, int action, double improvement) {
-  // learning.rs:21-88; rel_improvement / immediate_weight are the host-evaluated :37-54
-  const double combined = S.immediate_weight * improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
-  const double adj = combined > 0.0 ? 1.0 + (S.learning_rate * combined)
-                                    : 1.0 / (1.0 + (S.learning_rate * dabs(combined)));
-  wave_sync();
-  if (lane == 0) SM_W[action] = dmin(dmax(SM_W[action] * adj, kMinWeight), kMaxWeight);
-  wave_sync();
-  if (combined < 0.0) {
-    const double boost = 1.0 + (S.learning_rate * 0.1);
-    if (lane < kFirstOffset && lane != action) SM_W[lane] = dmin(SM_W[lane] * boost, kMaxWeight);
-    wave_sync();
-    if (S.noop_boost && lane == 0) SM_W[kNothing] = dmin(SM_W[kNothing] * (1.0 + S.learning_rate * 0.2), kMaxWeight);
-    wave_sync();
-  }
-}
 __device__ void update_deficit_weights(const DevSnapshot& S, int lane, int action, double improvement) {
   // deficit.rs:82-135; every action that reaches here is AddGenerator(type, 100 %)
   int slot = -1;
@@ -667,6 +651,36 @@ __device__ void update_deficit_weights(const DevSnapshot& S, int lane, int actio
     if (lane < 14 && lane != slot) SM_DW[lane] = dmin(SM_DW[lane] * boost, kMaxWeight);
     wave_sync();
   }
+}
+
+// update_deficit_weights(action, d_improvement) followed by update_weights(action, w_improvement), as the repair loop calls
+// them after every applied action (simulation.rs:453-486).  Every table entry receives at most one factor from each
+// call (its own adjustment, or the "boost the others" factor, or the do-nothing boost), so both calls become one
+// lane-parallel pass — lane l owns w[l] and dw[l] — with the same multiplications and clamps per entry.
+__device__ __forceinline__ void nudge_after_repair(const DevSnapshot& S, int lane, int action, double d_improvement, double w_improvement) {
+  int slot = -1;
+  if (action < kFirstOffset && (action % 3) == 0) slot = c_deficit_slot[action / 3];
+  else if (action == kNothing) slot = 14;
+  const double lr = S.learning_rate;
+  const double adj_d = d_improvement > 0.0 ? 1.0 + (lr * d_improvement * 1.5) : 1.0 / (1.0 + (lr * dabs(d_improvement) * 1.5));
+  const double combined = S.immediate_weight * w_improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
+  const double adj_w = combined > 0.0 ? 1.0 + (lr * combined) : 1.0 / (1.0 + (lr * dabs(combined)));
+  const double boost = 1.0 + (lr * 0.1);
+  wave_sync();
+  if (lane < EG_N_ACTIONS) {
+    double v = SM_W[lane];
+    if (lane == action) v = dmin(dmax(v * adj_w, kMinWeight), kMaxWeight);
+    else if (combined < 0.0 && lane < kFirstOffset) v = dmin(v * boost, kMaxWeight);
+    if (combined < 0.0 && S.noop_boost && lane == kNothing) v = dmin(v * (1.0 + lr * 0.2), kMaxWeight);
+    SM_W[lane] = v;
+  }
+  if (slot >= 0 && lane < EG_N_DEFICIT) {
+    double v = SM_DW[lane];
+    if (lane == slot) v = dmin(dmax(v * adj_d, kMinWeight), kMaxWeight);
+    else if (d_improvement < 0.0 && lane < 14) v = dmin(v * boost, kMaxWeight);
+    SM_DW[lane] = v;
+  }
+  wave_sync();
 }
 
 // ---- sampling (canonical table order; see include/eirgrid_hip.h) -------------------------------------------
@@ -1090,8 +1104,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         const double ci = nxt.net < 1000.0 ? q_cost : 0.0;
         const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
-        update_deficit_weights(S, lane, action, combined);
-        update_weights(S, lane, action, overall * 0.5);
+        nudge_after_repair(S, lane, action, combined, overall * 0.5);
         tot.scaled_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
         cur = nxt;
