@@ -46,6 +46,15 @@ constexpr int kNothing = 60, kFirstOffset = 45, kFirstOther = 57;
 // deficit-table slot -> generator type (core.rs:130-149) and the inverse
 __constant__ int c_deficit_type[14] = {8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14};
 __constant__ int c_deficit_slot[15] = {5, 6, 10, 11, 7, 9, -1, 1, 0, 4, 8, 3, 2, 12, 13};
+// the same map as an immediate (4 bits per generator type, 15 = none) for loops that cannot afford a constant-memory
+// round trip per element: slot of an action index, -1 if the deficit table has no entry for it
+__device__ __forceinline__ int deficit_slot_of(int action) {
+  constexpr unsigned long long kNibbles = 0xDC238401F97BA65ull;      // type 0 in the low nibble: 5, 6, 10, 11, 7, 9, 15, 1, 0, 4, 8, 3, 2, 12, 13
+  if (action == 60) return 14;                                        // DoNothing
+  if (action >= 45 || action % 3 != 0) return -1;
+  const int s = (int)((kNibbles >> (4 * (action / 3))) & 15ull);
+  return s == 15 ? -1 : s;
+}
 
 struct __align__(16) Smem {
   double dr[kRadiusClasses * 169];    // d/R by (|di|, |dj|) for every radius class; 1.0 where d >= R
@@ -635,32 +644,12 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
-__device__ void update_deficit_weights(const DevSnapshot& S, int lane, int action, double improvement) {
-  // deficit.rs:82-135; every action that reaches here is AddGenerator(type, 100 %)
-  int slot = -1;
-  if (action < kFirstOffset && (action % 3) == 0) slot = c_deficit_slot[action / 3];
-  else if (action == kNothing) slot = 14;
-  if (slot < 0) return;
-  const double adj = improvement > 0.0 ? 1.0 + (S.learning_rate * improvement * 1.5)
-                                       : 1.0 / (1.0 + (S.learning_rate * dabs(improvement) * 1.5));
-  wave_sync();
-  if (lane == 0) SM_DW[slot] = dmin(dmax(SM_DW[slot] * adj, kMinWeight), kMaxWeight);
-  wave_sync();
-  if (improvement < 0.0) {
-    const double boost = 1.0 + (S.learning_rate * 0.1);
-    if (lane < 14 && lane != slot) SM_DW[lane] = dmin(SM_DW[lane] * boost, kMaxWeight);
-    wave_sync();
-  }
-}
-
 // update_deficit_weights(action, d_improvement) followed by update_weights(action, w_improvement), as the repair loop calls
 // them after every applied action (simulation.rs:453-486).  Every table entry receives at most one factor from each
 // call (its own adjustment, or the "boost the others" factor, or the do-nothing boost), so both calls become one
 // lane-parallel pass — lane l owns w[l] and dw[l] — with the same multiplications and clamps per entry.
 __device__ __forceinline__ void nudge_after_repair(const DevSnapshot& S, int lane, int action, double d_improvement, double w_improvement) {
-  int slot = -1;
-  if (action < kFirstOffset && (action % 3) == 0) slot = c_deficit_slot[action / 3];
-  else if (action == kNothing) slot = 14;
+  const int slot = deficit_slot_of(action);
   const double lr = S.learning_rate;
   const double adj_d = d_improvement > 0.0 ? 1.0 + (lr * d_improvement * 1.5) : 1.0 / (1.0 + (lr * dabs(d_improvement) * 1.5));
   const double combined = S.immediate_weight * w_improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
@@ -966,7 +955,22 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
           if (fin.balance >= 0.0 && success > 0.0 && ep.n_def_y > 0) {
             const double factor = 0.1 * success;
             wave_sync();
-            for (int i = 0; i < ep.n_def_y; ++i) update_deficit_weights(S, lane, sm.ydef[i], factor);
+            // update_deficit_weights(action_i, factor) for every deficit action of the year, in order (simulation.rs:505-519):
+            // factor > 0, so each call only multiplies its own slot and clamps — lane s counts the calls that hit slot s
+            // and applies that many multiply-and-clamp steps to dw[s] (the entries do not interact)
+            int hits = 0;
+            const int mine0 = sm.ydef[lane], mine1 = sm.ydef[64 + lane];      // the year's deficit actions, one per lane
+            for (int i = 0; i < ep.n_def_y; ++i) {
+              const int da = i < kWave ? __builtin_amdgcn_readlane(mine0, i) : __builtin_amdgcn_readlane(mine1, i - kWave);
+              hits += deficit_slot_of(da) == lane ? 1 : 0;
+            }
+            const double adj = 1.0 + (S.learning_rate * factor * 1.5);
+            if (lane < EG_N_DEFICIT && hits > 0) {
+              double v = SM_DW[lane];
+              for (int k = 0; k < hits; ++k) v = dmin(dmax(v * adj, kMinWeight), kMaxWeight);
+              SM_DW[lane] = v;
+            }
+            wave_sync();
           }
           phase = 1;
           continue;
