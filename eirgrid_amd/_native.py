@@ -62,7 +62,7 @@ EXPORTS = [
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
     "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
-    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history",
+    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history", "eg_policy_export_improvement_csv",
 ]
 
 _lib = None
@@ -122,6 +122,8 @@ def lib():
     L.eg_policy_pull.argtypes = [C.c_void_p, C.c_void_p]
     L.eg_policy_append_weight_history.restype = C.c_int32
     L.eg_policy_append_weight_history.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.eg_policy_export_improvement_csv.restype = C.c_int32
+    L.eg_policy_export_improvement_csv.argtypes = [C.c_void_p, C.c_char_p]
     L.eg_place.restype = C.c_int32
     L.eg_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u16p, C.c_int32, _i32p, _dp]
     L.eg_host_tables_create.restype = C.c_void_p

@@ -249,6 +249,27 @@ int32_t eg_policy_append_weight_history(const eg_policy* p, const char* path, ui
   return f.good() ? EG_OK : EG_ERR_BAD_ARG;
 }
 
+// improvement_history.csv of the best-run export (utils/csv_export.rs:155-207): one row per recorded improvement, the
+// score improvement relative to the previous record in per cent.  Nothing is written when there is no history.
+int32_t eg_policy_export_improvement_csv(const eg_policy* p, const char* path) {
+  if (!p || !path) return EG_ERR_BAD_ARG;
+  if (p->improvement_history.empty()) return EG_OK;
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) { eg::set_error(std::string("eg_policy_export_improvement_csv: cannot open ") + path); return EG_ERR_BAD_ARG; }
+  f << "Iteration,Score,Net Emissions (tonnes),Total Cost (\xE2\x82\xAC),Public Opinion (%),Power Reliability (%),Score Improvement (%),Timestamp\n";
+  double prev = 0.0;
+  char line[512];
+  for (size_t i = 0; i < p->improvement_history.size(); ++i) {
+    const ImprovementRecord& r = p->improvement_history[i];
+    const double improvement = (i > 0 && prev > 0.0) ? ((r.score - prev) / prev) * 100.0 : 0.0;
+    std::snprintf(line, sizeof(line), "%u,%.6f,%.2f,%.2f,%.2f,%.2f,%.2f,%s\n", r.iteration, r.score, r.net_emissions, r.total_cost,
+                  r.public_opinion * 100.0, r.power_reliability * 100.0, improvement, r.timestamp.c_str());
+    f << line;
+    prev = r.score;
+  }
+  return f.good() ? EG_OK : EG_ERR_BAD_ARG;
+}
+
 eg_policy* eg_policy_load_json(const char* path) {   // ai/learning/weights/serialization.rs:140-493
   if (!path) return nullptr;
   std::ifstream f(path, std::ios::binary);

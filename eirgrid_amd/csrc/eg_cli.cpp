@@ -7,7 +7,7 @@
 // absent, :38-39, :437-465).  Iterations run on the GPU in batches that share one weights snapshot — the GPU
 // counterpart of rayon workers cloning the shared weights (:457-460) — and are folded into the weights either one by
 // one in index order (--update sequential: multi_simulation.rs:494-508 verbatim) or with the batch form
-// (--update reduced, default).  CSV export (--enable-csv-export) is accepted and not implemented (N3).
+// (--update reduced, default).  Of the best-run CSV export (--enable-csv-export, N3) only improvement_history.csv is written.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -191,7 +191,7 @@ int main(int argc, char** argv) {
   if (!parse(argc, argv, a)) return 2;
   std::puts("EirGrid Power System Simulator (2025-2050) — MI355X rollout engine");
   if (a.enable_construction_delays) { std::fprintf(stderr, "error: --enable-construction-delays is not implemented on the device (DESIGN.md §6)\n"); return 2; }
-  if (a.enable_csv_export) std::puts("note: CSV export of the best run (N3) is not implemented; best_weights.json is written");
+  if (a.enable_csv_export) std::puts("note: of the best-run CSV export (N3) only enhanced_csv/<timestamp>/improvement_history.csv is written");
 
   WorldData wd;
   if (!a.world_json.empty()) { if (!load_world_json(a.world_json, wd)) { std::fprintf(stderr, "error: cannot read world %s\n", a.world_json.c_str()); return 1; } }
@@ -288,6 +288,13 @@ int main(int argc, char** argv) {
     }
   }
   CHECK(eg_policy_save_json(policy, (run_dir + "/best_weights.json").c_str()));   // multi_simulation.rs:1160-1164
+  if (a.enable_csv_export) {   // multi_simulation.rs:852-859, :912-921; csv_export.rs:114-127 (directory named after the time of export)
+    char stamp[32]; std::time_t t = std::time(nullptr); std::tm tmv; localtime_r(&t, &tmv);
+    std::strftime(stamp, sizeof(stamp), "%Y%m%d_%H%M%S", &tmv);
+    const std::string dir = run_dir + "/enhanced_csv/" + stamp;
+    mkdirs(dir);
+    CHECK(eg_policy_export_improvement_csv(policy, (dir + "/improvement_history.csv").c_str()));
+  }
   std::printf("Done: %llu iterations in %s; best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
               (unsigned long long)done, run_dir.c_str());
   eg_policy_free(policy);

@@ -246,7 +246,9 @@ int32_t eg_policy_save_json(const eg_policy *, const char *path);
 eg_policy *eg_policy_load_json(const char *path);
 /* --track-weight-history (core/multi_simulation.rs:166-207): append one snapshot {best_score, iteration, timestamp,
  * weights: ActionWeights::to_json()} to the pretty-printed JSON array in `path` (created as needed). */
-int32_t eg_policy_append_weight_history(const eg_policy *, const char *path, uint64_t iteration);   /* NULL + eg_last_error() on failure */
+int32_t eg_policy_append_weight_history(const eg_policy *, const char *path, uint64_t iteration);
+/* improvement_history.csv of the reference's best-run export (utils/csv_export.rs:155-207); no file if there is no history */
+int32_t eg_policy_export_improvement_csv(const eg_policy *, const char *path);   /* NULL + eg_last_error() on failure */
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus

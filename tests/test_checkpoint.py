@@ -118,3 +118,23 @@ def test_weight_history_snapshots(built, tmp_path):
     assert len(w["deficit_weights"]["2050"]) == 15 and "AddGenerator(GasPeaker, 100%)" in w["deficit_weights"]["2050"]
     assert text.startswith("[\n  {\n    \"best_score\": 0.0,\n    \"iteration\": 4,") and text.endswith("\n  }\n]")
     assert snap["timestamp"][10] == "T" and snap["timestamp"][-6] in "+-"
+
+
+def test_improvement_history_csv(built, tmp_path):
+    """utils/csv_export.rs:155-207: header, one row per improvement, score improvement in per cent of the previous score."""
+    from eirgrid_amd import _native as N
+    from eirgrid_amd.engine import ActionWeights
+    pol = ActionWeights()
+    path = tmp_path / "improvement_history.csv"
+    N.check(N.lib().eg_policy_export_improvement_csv(pol.h, str(path).encode()))
+    assert not path.exists()                              # no history, no file
+    ones, none = np.ones(26, np.int32), np.zeros(26, np.int32)
+    pol.apply_episode([5e5, 0.6, 9e11, 1.0], ones, np.full(26, 60, np.uint8), none, np.zeros(0, np.uint8))       # score 0.5
+    pol.apply_episode([2.5e5, 0.7, 8e11, 1.0], ones, np.full(26, 60, np.uint8), none, np.zeros(0, np.uint8))     # score 0.75
+    N.check(N.lib().eg_policy_export_improvement_csv(pol.h, str(path).encode()))
+    lines = path.read_text(encoding="utf-8").splitlines()
+    assert lines[0] == "Iteration,Score,Net Emissions (tonnes),Total Cost (€),Public Opinion (%),Power Reliability (%),Score Improvement (%),Timestamp"
+    r1, r2 = lines[1].split(","), lines[2].split(",")
+    assert r1[:7] == ["1", "0.500000", "500000.00", "900000000000.00", "60.00", "100.00", "0.00"]
+    assert r2[:7] == ["2", "0.750000", "250000.00", "800000000000.00", "70.00", "100.00", "50.00"]
+    assert len(lines) == 3
