@@ -129,6 +129,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world_size > 1 or args.force_collectives
+    # RCCL prints a version banner on stdout when its first communicator comes up (at the first collective).  stdout is
+    # reserved for the one JSON line: until the warm-up is over, file descriptor 1 points at stderr.
+    saved_stdout = None
+    if use_dist:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -152,6 +159,9 @@ def main():
         trainer.step()
     eng.sync(); eng.timing_reset()
     fence()
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1); os.close(saved_stdout)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.step()
