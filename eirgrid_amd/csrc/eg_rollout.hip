@@ -840,6 +840,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     // (the helper also brings the 8 KB factor table into LDS: it has nothing else to do until the first search, and the
     //  barrier of that search orders its LDS writes before anybody's reads)
     if (wave > 0) { load_factor_table(T, lane); helper_loop(T, lane, wave); return; }
+    __builtin_amdgcn_s_setprio(3);      // the episode wave is the critical path: it wins issue arbitration over helper waves
   }
   DevSnapshot S = S_in;
   load_state(S);
