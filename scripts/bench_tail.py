@@ -24,6 +24,9 @@ for k in range(steps):
     key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     counts = np.bincount(key.astype(np.int64))
     counts = counts[counts > 0]
+    simd = (hwid >> 4) & 3
+    per_simd = np.bincount((key * 4 + simd).astype(np.int64)); per_simd = per_simd[per_simd > 0]
+    print(f"step {k:2d} episode waves per SIMD: " + " ".join(f"{c}:{int((per_simd == c).sum())}" for c in sorted(set(per_simd.tolist()))) + f"  (SIMDs hosting one: {len(per_simd)} of {4 * len(counts)})")
     print(f"step {k:2d} CUs used {len(counts)}  workgroups per CU: " + " ".join(f"{c}:{int((counts == c).sum())}" for c in sorted(set(counts.tolist()))))
     print(f"step {k:2d} kernel {ms / max(n, 1):.3f} ms  episode cycles mean {tot.mean():8.0f} p50 {srt[B // 2]:8.0f} p99 {srt[int(B * 0.99)]:8.0f} max {srt[-1]:8.0f}  "
           f"max/2.4GHz {srt[-1] / 2.4e6:.3f} ms  placement of slowest {st[int(np.argmax(tot)), 1]:8.0f} gens {res.n_gens[int(np.argmax(tot))]}", flush=True)
