@@ -189,7 +189,8 @@ def main():
                                    "(grid step + tabular policy sampling + batch policy update), synthetic world "
                                    "S=130 settlements / G0=59 existing plant / P=200 coast points, fresh ActionWeights, seed 12345",
                        "episodes_per_gpu_per_step": args.episodes, "replay_fraction": args.replay_fraction,
-                       "parallelism": f"episode-sharded dp{world_size}, one int64 stats all-reduce per update",
+                       "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one 32 KB all-gather per update "
+                                      "(integer statistics summed in the update kernel)",
                        "episodes_ok_last_batch": ok, "strategy_improvements": trainer.improvements},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.episodes), "kernel": "k_rollout",
