@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Headline benchmark: full 26-year episodes/s of the rollout hot path on N MI355X (BASELINE.json `metric`).
 
-A step = one pass of the hot path over one batch: rollout of `--episodes` episodes per GPU against the current policy
-snapshot (k_rollout), the batch update statistics (k_update_stats), the per-update exchange (one RCCL sum all-reduce of
-the int64 statistics + best-candidate gather/broadcast when N > 1) and the host-side policy update + snapshot upload.
-Inputs (world tables, snapshot) are resident in HBM when the timed region starts.  Weak scaling: every rank runs
-`--episodes` episodes per step with streams keyed by global episode index.
+A step = one pass of the hot path over one batch, with the policy resident on the device: rollout of `--episodes`
+episodes per GPU against the current policy (k_rollout, batch-update statistics in its epilogue), best-episode pick
+(k_pick_best), when N > 1 the per-update exchange (ONE RCCL all-gather of every rank's 32 KB update packet), the batch
+update itself (k_apply_update) and the stalled-sampler tables (k_stalled_tables) — stream-ordered launches, no host
+synchronisation inside the timed region.  Inputs (world tables, policy) are resident in HBM when the timed region starts.
+Weak scaling: every rank runs `--episodes` episodes per step with streams keyed by global episode index.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
