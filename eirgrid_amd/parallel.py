@@ -2,10 +2,12 @@
 
 Episodes are independent given a policy snapshot, so a batch is sharded by global episode index with no data-path
 collective.  The only exchange is the per-update one of SURVEY.md §8(e):
-  * ONE sum all-reduce of the int64 update-statistics buffer (EG_STATS_LEN * 8 B ≈ 28 KB, latency-bound);
-  * best-candidate selection: an all-gather of one (score, global index) pair per rank, then the owner broadcasts the
-    winning episode's metrics + action lists (≈3 KB).
-Every rank then applies the identical update to its own copy of ActionWeights (integer statistics ⇒ bit-identical
+  * device-resident policy (BatchTrainer's default under RCCL): ONE all-gather of every rank's 32 KB update packet
+    (int64 statistics + the rank's best-candidate record); k_apply_update on every rank adds the statistics (integers:
+    the sum is the all-reduce) and picks the winning candidate — no host synchronisation in the step;
+  * host-side policy (gloo rehearsals, exchange_packet_raw / exchange_update): a sum all-reduce of the statistics and an
+    all-gather of the candidate records, then eg_policy_apply_packet on every rank.
+Either way every rank applies the identical update to its own copy of the policy (integer statistics ⇒ bit-identical
 replicas, no weight broadcast).  torch is used for device memory, the stream and the collectives only.
 """
 from __future__ import annotations
@@ -129,7 +131,7 @@ class BatchTrainer:
     """Rollout + batch update loop of one rank (the driver of configs 2-4).
 
     device_resident (default on one GPU and under RCCL): the policy is pushed to the device once and every step is
-    enqueued without a host synchronisation — rollout with the statistics epilogue, best pick, (all-reduce + all-gather,)
+    enqueued without a host synchronisation — rollout with the statistics epilogue, best pick, (one all-gather,)
     k_apply_update, stalled tables; `weights` is refreshed by sync().  Otherwise (gloo rehearsals on the CPU side of
     the exchange) each step uploads the snapshot, copies the packet to the host and updates `weights` there.  Both
     leave the same policy behind, bit for bit (tests/test_gpu_update.py)."""
@@ -147,7 +149,7 @@ class BatchTrainer:
         self.replay_period = max(1, int(round(1.0 / replay_fraction))) if replay_fraction > 0.0 else 0
         self.write_yearly = write_yearly
         self.step_index = 0
-        # force_collectives: run the all-reduce / all-gather even with one rank (exercises the RCCL path on one GPU)
+        # force_collectives: run the all-gather even with one rank (exercises the RCCL path on one GPU)
         multi = dist is not None and (world_size > 1 or force_collectives)
         self.multi = multi
         if device_resident is None:
