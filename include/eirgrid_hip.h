@@ -10,6 +10,11 @@
  *   eg_place                    MetalLocationSearch::find_suitable_location   gpu/metal_location_search.rs:96-103
  *   eg_policy_*                 ActionWeights::{new, update_*, apply_*}        ai/learning/weights/ (all files)
  *   eg_policy_apply_episode     the write-locked section               core/multi_simulation.rs:494-508
+ *   eg_train_step, eg_policy_push / eg_device_step / eg_policy_pull    the body of the training loop (one batch of
+ *                               iterations + the update), on the host or entirely on the device   multi_simulation.rs:425-508
+ *   eg_policy_save_json / load_json / append_weight_history / export_improvement_csv
+ *                               checkpoints and run-directory files    ai/learning/weights/serialization.rs,
+ *                                                                       multi_simulation.rs:166-207, utils/csv_export.rs:155-207
  *
  * Conventions: plain pointers and sizes, caller-allocated host buffers unless a parameter is named d_* (device
  * pointer).  Every function returning int32_t returns EG_OK (0) or a negative EG_ERR_* code; eg_last_error()
