@@ -352,6 +352,20 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   return EG_OK;
 }
 
+int32_t eg_debug_fill_lds(eg_ctx* c, uint32_t value) {
+  if (!c) { set_error("eg_debug_fill_lds: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  int rc = ensure_outputs(c, 1);
+  if (rc != EG_OK) return rc;
+  hipDeviceProp_t prop;
+  EG_HIP(hipGetDeviceProperties(&prop, c->device));
+  // 64 KB per workgroup: at most two share a CU's 160 KB, so 4 per CU in flight-order covers every slot several times
+  int lr = launch_fill_lds(value, reinterpret_cast<uint32_t*>(c->out.base), prop.multiProcessorCount * 8, nullptr);
+  if (lr != 0) { set_error(std::string("k_fill_lds launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  EG_HIP(hipDeviceSynchronize());
+  return EG_OK;
+}
+
 int32_t eg_sync(eg_ctx* c) {
   if (!c) return EG_ERR_BAD_ARG;
   EG_HIP(hipSetDevice(c->device));

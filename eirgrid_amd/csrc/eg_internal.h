@@ -226,6 +226,7 @@ struct UpdateCandidate;
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
                    bool helper_waves, void* ev_start, void* ev_stop);
+int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
 int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,

@@ -841,6 +841,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     //  barrier of that search orders its LDS writes before anybody's reads)
     if (wave > 0) { load_factor_table(T, lane); helper_loop(T, lane, wave); return; }
     __builtin_amdgcn_s_setprio(3);      // the episode wave is the critical path: it wins issue arbitration over helper waves
+    // LDS arrives with whatever the previous workgroup on this CU left in it: a stale word that happens to equal a
+    // sequence number would read as "result ready".  The flags start at 0 (sequence numbers start at 1); the helper
+    // cannot touch them before the first command's barrier, which also orders these writes.
+#ifndef EG_TEST_NO_FLAG_INIT
+    if (lane == 0) { sm.hflag[0] = 0u; sm.hflag[1] = 0u; sm.yflag = 0u; }
+#endif
   }
   DevSnapshot S = S_in;
   load_state(S);
@@ -1495,6 +1501,18 @@ int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_
                  int32_t* d_out_cell, double* d_out_score, void* stream) {
   hipLaunchKernelGGL(k_place, dim3(1), dim3(kWave), 0, (hipStream_t)stream, t, gen_type, year_index, d_cells, n_extra,
                      d_out_cell, d_out_score);
+  return (int)hipGetLastError();
+}
+// Test hook: leaves `value` in every LDS word a later workgroup can be handed (tests/test_gpu_parity.py uses it to show
+// that no kernel reads LDS it has not written).  One workgroup of 64 KB per slot, enough of them to cover every CU.
+__global__ void __launch_bounds__(256) k_fill_lds(uint32_t value, uint32_t* sink) {
+  __shared__ uint32_t words[16384];
+  for (int i = threadIdx.x; i < 16384; i += 256) words[i] = value;
+  __syncthreads();
+  if (words[(threadIdx.x * 61u + blockIdx.x) & 16383u] != value) *sink = 1u;      // keeps the stores alive
+}
+int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream) {
+  hipLaunchKernelGGL(k_fill_lds, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, value, d_sink);
   return (int)hipGetLastError();
 }
 int launch_stalled_tables(uint8_t* d_snap, void* stream) {

@@ -348,6 +348,10 @@ class Engine:
                                                _p(nd, C.c_int32), _p(dl, C.c_uint8)), "eg_fetch_episode_lists")
         return m, nr, rl, nd, dl
 
+    def debug_fill_lds(self, value: int) -> None:
+        """Test hook: leave `value` in every LDS word of every CU (LDS is not cleared between workgroups)."""
+        N.check(N.lib().eg_debug_fill_lds(self.h, C.c_uint32(value & 0xFFFFFFFF)), "eg_debug_fill_lds")
+
     def find_suitable_location(self, gen_type: int, year_index: int = 0, extra_cells=()):
         """gpu/metal_location_search.rs:96-103 on the device: returns (cell or -1, best score)."""
         cells = np.ascontiguousarray(list(extra_cells), dtype=np.uint16)

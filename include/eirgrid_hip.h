@@ -185,6 +185,11 @@ int32_t eg_fetch_scores(eg_ctx *, double *scores);
 int32_t eg_fetch_episode_lists(eg_ctx *, uint32_t episode, double metrics[4], int32_t *n_run, uint8_t *run_log /* EG_RUN_CAP */,
                                int32_t *n_def, uint8_t *def_log /* EG_DEF_CAP */);
 
+/* Test hook: fills the LDS of every compute unit with `value` and waits.  LDS is not cleared between workgroups, so a
+ * kernel that reads a word before writing it sees what the previous tenant left; the parity tests call this with small
+ * integers (the values the helper protocol's sequence flags take) before a rollout. */
+int32_t eg_debug_fill_lds(eg_ctx *, uint32_t value);
+
 /* B2: one placement search on the device (settlements of year index `year_index`, the ctx's existing plant plus
  * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */
 int32_t eg_place(eg_ctx *, int32_t gen_type, int32_t year_index, const uint16_t *extra_cells, int32_t n_extra,

@@ -226,8 +226,8 @@ def test_fuzzed_snapshots_and_replay_fallbacks(engine, world):
 
 
 def test_helper_wave_kernel_equals_single_wave_kernel(world):
-    """Small batches run three waves per episode (two helper waves evaluate chunks 1 and 2 of every placement search);
-    large batches run one.  Both kernels, forced through the same 1,536 episodes (fresh and stalled policy, with
+    """Small batches run two waves per episode (a helper wave evaluates chunk 1 of every placement search and folds the
+    next year's sums); large batches run one.  Both kernels, forced through the same 1,536 episodes (fresh and stalled policy, with
     replays), must agree on every output byte — and a sample of them with the tabled oracle."""
     tb = _tabled(world)
     engines = {}
@@ -258,3 +258,27 @@ def test_helper_wave_kernel_equals_single_wave_kernel(world):
     finally:
         for eng in engines.values():
             eng.close()
+
+
+def test_rollout_ignores_what_is_left_in_lds(engine, world):
+    """LDS is handed from workgroup to workgroup uncleared.  The helper protocol polls sequence flags in LDS, so a stale
+    word equal to a live sequence number would read as "result ready" (seen once as a garbage year-1 opinion after a
+    kernel that leaves small integers in LDS).  Fill every CU's LDS with each value a flag takes early in an episode,
+    then roll out: every output byte must equal the clean run's."""
+    pol = ActionWeights()
+    n = 1024                                         # the two-wave kernel
+    clean = engine.rollout_batch(pol, 97531, n)
+    tb = _tabled(world)
+    for e in range(0, n, 101):
+        st, ref = O.run_episode_tabled(tb, O.OracleWeights(), 97531 + e)
+        assert_episode_equal(clean, e, ref, "clean run")
+    names = ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "run_log", "def_log", "act_log", "gen_cell")
+    for value in list(range(1, 25)) + [0xFFFFFFFF, 0x3FF00000]:
+        engine.debug_fill_lds(value)
+        res = engine.rollout_batch(pol, 97531, n)
+        for name in names:
+            assert getattr(res, name).tobytes() == getattr(clean, name).tobytes(), (value, name)
+    engine.debug_fill_lds(3)
+    big = engine.rollout_batch(pol, 97531, 4096)     # the one-wave kernel on the same episodes
+    for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_draws"):
+        assert getattr(big, name)[:n].tobytes() == getattr(clean, name).tobytes(), name
