@@ -57,12 +57,12 @@ class EgEpisodeOut(C.Structure):
 EXPORTS = [
     "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
     "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
-    "eg_fetch_episode_lists", "eg_place", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
+    "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_place", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
     "eg_policy_push", "eg_device_rollout", "eg_device_apply", "eg_device_step", "eg_policy_pull",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
     "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
-    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history", "eg_policy_export_improvement_csv",
+    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history", "eg_policy_export_improvement_csv", "eg_export_summary_csv",
 ]
 
 _lib = None
@@ -123,6 +123,12 @@ def lib():
     L.eg_policy_append_weight_history.restype = C.c_int32
     L.eg_policy_append_weight_history.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     L.eg_policy_export_improvement_csv.restype = C.c_int32
+    L.eg_export_summary_csv.restype = C.c_int32
+    L.eg_export_summary_csv.argtypes = [C.POINTER(EgEpisodeOut), C.c_char_p, C.c_char_p]
+    L.eg_fetch_record.restype = C.c_int32
+    L.eg_fetch_record.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(EgEpisodeOut)]
+    L.eg_fetch_best_run.restype = C.c_int32
+    L.eg_fetch_best_run.argtypes = [C.c_void_p, C.POINTER(EgEpisodeOut), C.POINTER(C.c_int32)]
     L.eg_policy_export_improvement_csv.argtypes = [C.c_void_p, C.c_char_p]
     L.eg_place.restype = C.c_int32
     L.eg_debug_fill_lds.restype = C.c_int32

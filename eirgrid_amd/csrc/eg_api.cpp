@@ -64,6 +64,7 @@ struct eg_ctx {
   // outputs
   DevOut out{};
   uint32_t out_cap = 0, last_n = 0;
+  uint64_t last_first = 0;      // global index of the first episode of the last batch
   uint8_t* d_mask = nullptr; uint32_t mask_cap = 0;
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -201,7 +202,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   if (rc == EG_OK) {
     if (hipMalloc((void**)&c->d_snap, snap::total) != hipSuccess || hipHostMalloc((void**)&c->h_snap, snap::total) != hipSuccess) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
-    }
+    } else if (hipMemset(c->d_snap, 0, snap::total) != hipSuccess) { set_error("hipMemset(snapshot) failed"); rc = EG_ERR_HIP; }
   }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
@@ -325,7 +326,7 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   c->timing_pending = true;
-  c->last_n = n;
+  c->last_n = n; c->last_first = first_index;
   return EG_OK;
 }
 
@@ -346,7 +347,7 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   c->timing_pending = true;
-  c->last_n = n;
+  c->last_n = n; c->last_first = first_index;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
@@ -373,15 +374,11 @@ int32_t eg_sync(eg_ctx* c) {
   return collect_timing(c);
 }
 
-int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
-  if (!c || !o) return EG_ERR_BAD_ARG;
-  int rc = eg_sync(c);
-  if (rc != EG_OK) return rc;
-  const size_t N = c->last_n;
-  if (N == 0) return EG_OK;
-  // one strided copy per requested field: episode records are rec::stride bytes apart on the device
+namespace {
+// one strided copy per requested field: episode records are rec::stride bytes apart on the device
+int fetch_records(const uint8_t* d_base, size_t N, eg_episode_out* o) {
 #define EG_GET(field, count, type) \
-  if (o->field) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), c->out.base + rec::field, rec::stride, (count) * sizeof(type), N, hipMemcpyDeviceToHost))
+  if (o->field) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), d_base + rec::field, rec::stride, (count) * sizeof(type), N, hipMemcpyDeviceToHost))
   EG_GET(metrics, 4, double); EG_GET(yearly, EG_YEARS * EG_YEARLY_FIELDS, double); EG_GET(status, 1, int32_t);
   EG_GET(n_run, EG_YEARS, int32_t); EG_GET(n_def, EG_YEARS, int32_t); EG_GET(n_act, EG_YEARS, int32_t);
   EG_GET(run_log, EG_RUN_CAP, uint8_t); EG_GET(def_log, EG_DEF_CAP, uint8_t); EG_GET(act_log, EG_ACT_CAP, uint8_t);
@@ -391,6 +388,33 @@ int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
   EG_GET(n_draws, 1, uint64_t);
 #undef EG_GET
   return EG_OK;
+}
+}  // namespace
+
+int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
+  if (!c || !o) return EG_ERR_BAD_ARG;
+  int rc = eg_sync(c);
+  if (rc != EG_OK) return rc;
+  if (c->last_n == 0) return EG_OK;
+  return fetch_records(c->out.base, c->last_n, o);
+}
+
+int32_t eg_fetch_record(eg_ctx* c, uint32_t episode, eg_episode_out* o) {
+  if (!c || !o || episode >= c->last_n) { set_error("eg_fetch_record: bad argument"); return EG_ERR_BAD_ARG; }
+  int rc = eg_sync(c);
+  if (rc != EG_OK) return rc;
+  return fetch_records(c->out.base + size_t(episode) * rec::stride, 1, o);
+}
+
+int32_t eg_fetch_best_run(eg_ctx* c, eg_episode_out* o, int32_t* state) {
+  if (!c || !o || !state || !c->snap_valid) { set_error("eg_fetch_best_run: push a policy first"); return EG_ERR_BAD_ARG; }
+  int rc = eg_sync(c);
+  if (rc != EG_OK) return rc;
+  uint32_t word = 0;
+  EG_HIP(hipMemcpy(&word, c->d_snap + snap::best_rec_state, sizeof(word), hipMemcpyDeviceToHost));
+  *state = (int32_t)word;
+  if (word != 1u) return EG_OK;
+  return fetch_records(c->d_snap + snap::best_rec, 1, o);
 }
 
 int32_t eg_train_step(eg_ctx* c, eg_policy* p, const eg_opts* o, uint64_t seed, uint64_t first_index, uint32_t n,
@@ -454,7 +478,7 @@ int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
                           n <= c->helper_max_episodes, c->ev0, c->ev1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   c->timing_pending = true;
-  c->last_n = n;
+  c->last_n = n; c->last_first = first_index;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
@@ -463,7 +487,7 @@ int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
 int32_t eg_device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed) {
   if (!c || !c->snap_valid || !d_packets || n_packets < 1 || !d_own_packet) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, nullptr);
+  int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, c->out, c->last_n, c->last_first, nullptr);
   if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   lr = launch_stalled_tables(c->d_snap, nullptr);
   if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -493,7 +517,7 @@ int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
     for (int i = 0; i < EG_N_DEFICIT; ++i) p->dw[y][i] = row[snap::kPolDw + i];
   }
   p->stall = st.stall; p->iteration_count = st.iteration_count;
-  if (st.n_improvements > c->pulled_improvements) {      // at least one on-device improvement since the last pull
+  if (st.n_improvements > 0) {      // at least one on-device improvement since the push: the best strategy is the device's
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = st.best_metrics[i];
     const int32_t* off = reinterpret_cast<const int32_t*>(h.data() + snap::best_off);
     const int32_t* offd = reinterpret_cast<const int32_t*>(h.data() + snap::bestd_off);
@@ -504,6 +528,8 @@ int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
     }
     p->has_best_actions = true; p->has_best_deficit = true; p->has_best_weights = true;
     std::memcpy(p->best_w.data(), h.data() + snap::best_w, sizeof(double) * EG_YEARS * EG_N_ACTIONS);
+  }
+  if (st.n_improvements > c->pulled_improvements) {      // history records are appended once per context, whichever policy pulls
     const DevImprovement* log = reinterpret_cast<const DevImprovement*>(h.data() + snap::imp_log);
     uint32_t from = c->pulled_improvements;
     if (st.n_improvements - from > uint32_t(snap::kImpLogCap)) from = st.n_improvements - uint32_t(snap::kImpLogCap);   // ring overwrote older ones

@@ -9,6 +9,7 @@
 // actions follow the canonical table order.  A file written here loads in the reference's load_from_file, and a
 // file written by the reference loads here.
 #include <cerrno>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +47,13 @@ std::string fmt_f64(double v) {   // shortest representation that round-trips, w
   std::string s(buf);
   if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
   return s;
+}
+std::string fmt_display(double v) {      // Rust `{}` of an f64: shortest digits that round-trip, never an exponent, "5" for 5.0
+  if (std::isnan(v)) return "NaN";
+  if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+  char buf[400];
+  auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
+  return std::string(buf, r.ptr);
 }
 struct Writer {
   std::string out; int depth = 0;
@@ -266,6 +274,54 @@ int32_t eg_policy_export_improvement_csv(const eg_policy* p, const char* path) {
                   r.public_opinion * 100.0, r.power_reliability * 100.0, improvement, r.timestamp.c_str());
     f << line;
     prev = r.score;
+  }
+  return f.good() ? EG_OK : EG_ERR_BAD_ARG;
+}
+
+// simulation_summary.csv of the best-run export (utils/csv_export.rs:215-432): final metrics, one row per action of
+// SimulationResult.actions with the exporter's cost estimate, one row per year of YearlyMetrics.  `run` holds ONE episode
+// (the record eg_fetch_best_run / eg_fetch_record return; metrics, yearly, n_act and act_log are read).
+int32_t eg_export_summary_csv(const eg_episode_out* run, const char* path, const char* timestamp) {
+  if (!run || !path || !run->metrics || !run->yearly || !run->n_act || !run->act_log) {
+    eg::set_error("eg_export_summary_csv: metrics, yearly, n_act and act_log are required"); return EG_ERR_BAD_ARG;
+  }
+  std::ofstream f(path, std::ios::binary | std::ios::trunc);
+  if (!f) { eg::set_error(std::string("eg_export_summary_csv: cannot open ") + path); return EG_ERR_BAD_ARG; }
+  char line[1024];
+  f << "Simulation Summary\n" << "Timestamp," << (timestamp ? timestamp : "") << "\n\n";
+  f << "Final Metrics\n";
+  f << "Final Net Emissions (tonnes CO2)," << fmt_display(run->metrics[0]) << "\n";
+  std::snprintf(line, sizeof(line), "Average Public Opinion (%%),%.2f\nTotal Cost (\xE2\x82\xAC),%.2f\nPower Reliability (%%),%.2f\n\n",
+                run->metrics[1] * 100.0, run->metrics[2], run->metrics[3] * 100.0);
+  f << line;
+  f << "Actions Taken\n";
+  f << "Year,Action Type,Generator Type,Generator ID,Operation %,Offset Type,Estimated Cost (\xE2\x82\xAC)\n";
+  size_t k = 0;
+  for (int y = 0; y < Y; ++y) {
+    for (int i = 0; i < run->n_act[y]; ++i, ++k) {
+      if (k >= size_t(EG_ACT_CAP)) { eg::set_error("eg_export_summary_csv: action list longer than EG_ACT_CAP"); return EG_ERR_BAD_ARG; }
+      const int a = run->act_log[k];
+      const char* kind = "DoNothing"; const char* gen = ""; const char* op = ""; const char* off = "";
+      if (a < 45) { kind = "AddGenerator"; gen = kTypeName[a / 3]; }
+      else if (a < 57) { kind = "AddCarbonOffset"; off = kOffsetName[(a - 45) / 3]; }
+      else if (a == 57) kind = "UpgradeEfficiency";
+      else if (a == 58) { kind = "AdjustOperation"; op = "0"; }      // AdjustOperation(String::new(), 0), core.rs:118
+      else if (a == 59) kind = "CloseGenerator";
+      std::snprintf(line, sizeof(line), "%d,%s,%s,,%s,%s,%.2f\n", 2025 + y, kind, gen, op, off, eg::action_cost_estimate(a, y));
+      f << line;
+    }
+  }
+  f << "\nYearly Summary Metrics\n";
+  f << "Year,Population,PowerUsage,PowerGeneration,PowerBalance,PublicOpinion,YearlyCapitalCost,TotalCapitalCost,Inflation,CO2Emissions,"
+       "CarbonOffset,NetEmissions,YearlyRevenue,TotalRevenue,ActiveGenerators,YearlyUpgradeCosts,YearlyClosureCosts,YearlyTotalCost,TotalCost\n";
+  for (int y = 0; y < Y; ++y) {
+    const double* r = run->yearly + size_t(y) * EG_YEARLY_FIELDS;
+    std::snprintf(line, sizeof(line), "%llu,%llu,%.2f,%.2f,%.2f,%.4f,%.2f,%.2f,%.4f,%.2f,%.2f,%.2f,%.2f,%.2f,%llu,%.2f,%.2f,%.2f,%.2f\n",
+                  (unsigned long long)r[EG_Y_YEAR], (unsigned long long)r[EG_Y_POP], r[EG_Y_USAGE], r[EG_Y_GEN], r[EG_Y_BALANCE], r[EG_Y_OPINION],
+                  r[EG_Y_YEARLY_CAPITAL], r[EG_Y_TOTAL_CAPITAL], r[EG_Y_INFLATION], r[EG_Y_CO2], r[EG_Y_OFFSET], r[EG_Y_NET_CO2],
+                  r[EG_Y_YEARLY_CREDIT], r[EG_Y_TOTAL_CREDIT], (unsigned long long)r[EG_Y_ACTIVE_GENS], r[EG_Y_UPGRADE_COSTS],
+                  r[EG_Y_CLOSURE_COSTS], r[EG_Y_YEARLY_TOTAL_COST], r[EG_Y_TOTAL_COST]);
+    f << line;
   }
   return f.good() ? EG_OK : EG_ERR_BAD_ARG;
 }

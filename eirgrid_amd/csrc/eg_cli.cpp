@@ -7,7 +7,8 @@
 // absent, :38-39, :437-465).  Iterations run on the GPU in batches that share one weights snapshot — the GPU
 // counterpart of rayon workers cloning the shared weights (:457-460) — and are folded into the weights either one by
 // one in index order (--update sequential: multi_simulation.rs:494-508 verbatim) or with the batch form
-// (--update reduced, default).  Of the best-run CSV export (--enable-csv-export, N3) only improvement_history.csv is written.
+// (--update reduced, default).  Of the best-run CSV export (--enable-csv-export, N3) simulation_summary.csv and
+// improvement_history.csv are written; the per-settlement / per-generator detail files are not.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -191,7 +192,7 @@ int main(int argc, char** argv) {
   if (!parse(argc, argv, a)) return 2;
   std::puts("EirGrid Power System Simulator (2025-2050) — MI355X rollout engine");
   if (a.enable_construction_delays) { std::fprintf(stderr, "error: --enable-construction-delays is not implemented on the device (DESIGN.md §6)\n"); return 2; }
-  if (a.enable_csv_export) std::puts("note: of the best-run CSV export (N3) only enhanced_csv/<timestamp>/improvement_history.csv is written");
+  if (a.enable_csv_export) std::puts("note: the best-run CSV export (N3) writes enhanced_csv/<timestamp>/{simulation_summary,improvement_history}.csv; the yearly_details/ and operation_logs/ files are not written");
 
   WorldData wd;
   if (!a.world_json.empty()) { if (!load_world_json(a.world_json, wd)) { std::fprintf(stderr, "error: cannot read world %s\n", a.world_json.c_str()); return 1; } }
@@ -226,9 +227,16 @@ int main(int argc, char** argv) {
               (unsigned long long)a.iterations, (unsigned long long)start_iteration,
               (unsigned long long)(a.iterations > start_iteration ? a.iterations - start_iteration : 0), run_dir.c_str());
 
+  // record of the best episode (the reference's best_result, multi_simulation.rs:494-508), for the export at the end
+  struct BestRun {
+    std::vector<double> metrics = std::vector<double>(4), yearly = std::vector<double>(size_t(EG_YEARS) * EG_YEARLY_FIELDS);
+    std::vector<int32_t> n_act = std::vector<int32_t>(EG_YEARS); std::vector<uint8_t> act_log = std::vector<uint8_t>(EG_ACT_CAP);
+    eg_episode_out view{}; bool valid = false;
+    BestRun() { view.metrics = metrics.data(); view.yearly = yearly.data(); view.n_act = n_act.data(); view.act_log = act_log.data(); }
+  } best_run;
   std::vector<uint8_t> mask;
   std::vector<double> metrics; std::vector<int32_t> n_run, n_def; std::vector<uint8_t> run_log, def_log;
-  eg_opts opts{a.enable_energy_sales ? 1 : 0, 0, 0};
+  eg_opts opts{a.enable_energy_sales ? 1 : 0, 0, a.enable_csv_export ? 1 : 0};   // the export needs the best episode's yearly rows
   const uint64_t final_full = a.iterations * 10 / 100;   // FULL_RUN_PERCENTAGE, multi_simulation.rs:38, :437
   auto t0 = std::chrono::steady_clock::now(); auto last_progress = t0;
   uint64_t done = start_iteration, last_checkpoint = start_iteration / a.checkpoint_interval;
@@ -259,10 +267,15 @@ int main(int argc, char** argv) {
       out.def_log = def_log.data(); out.status = status.data();
       CHECK(eg_rollout_launch(ctx, a.seed, done, n, mask.data()));
       CHECK(eg_fetch(ctx, &out));
+      int best_in_batch = -1;
       for (uint32_t i = 0; i < n; ++i)   // multi_simulation.rs:494-508, in iteration order
-        if (status[i] == EG_EP_OK)
+        if (status[i] == EG_EP_OK) {
+          const double before = eg_policy_get_scalar(policy, 12);      // improvements recorded so far
           CHECK(eg_policy_apply_episode(policy, &metrics[size_t(i) * 4], &n_run[size_t(i) * EG_YEARS], &run_log[size_t(i) * EG_RUN_CAP],
                                         &n_def[size_t(i) * EG_YEARS], &def_log[size_t(i) * EG_DEF_CAP], a.seed + done + i));
+          if (eg_policy_get_scalar(policy, 12) != before) best_in_batch = int(i);
+        }
+      if (best_in_batch >= 0 && a.enable_csv_export) { CHECK(eg_fetch_record(ctx, uint32_t(best_in_batch), &best_run.view)); best_run.valid = true; }
     }
     done += n;
     const auto now = std::chrono::steady_clock::now();
@@ -294,6 +307,9 @@ int main(int argc, char** argv) {
     const std::string dir = run_dir + "/enhanced_csv/" + stamp;
     mkdirs(dir);
     CHECK(eg_policy_export_improvement_csv(policy, (dir + "/improvement_history.csv").c_str()));
+    if (reduced) { int32_t state = 0; CHECK(eg_fetch_best_run(ctx, &best_run.view, &state)); best_run.valid = state == 1; }
+    if (best_run.valid) CHECK(eg_export_summary_csv(&best_run.view, (dir + "/simulation_summary.csv").c_str(), stamp));
+    else std::puts("note: no improvement in this run; simulation_summary.csv not written");
   }
   std::printf("Done: %llu iterations in %s; best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
               (unsigned long long)done, run_dir.c_str());

@@ -159,7 +159,11 @@ constexpr size_t upload_bytes = state + sizeof(DevState);                   // w
 constexpr int kImpLogCap = 256;
 constexpr size_t best_w = (upload_bytes + 15) & ~size_t(15);                // f64 [26][61] main weights at the last improvement
 constexpr size_t imp_log = best_w + 8 * EG_YEARS * EG_N_ACTIONS;            // DevImprovement [kImpLogCap] (ring)
-constexpr size_t total = imp_log + sizeof(DevImprovement) * kImpLogCap;
+// Record (rec:: layout) of the best episode, kept by k_apply_update when that episode ran on this device, and its state
+// word: 0 = empty, 1 = holds the best episode's record, 2 = the best episode ran on another rank.  Outside the uploaded
+// range, so it survives eg_upload_snapshot / eg_policy_push on the same context.
+constexpr size_t best_rec_state = (imp_log + sizeof(DevImprovement) * kImpLogCap + 63) & ~size_t(63);   // u32
+constexpr size_t best_rec = best_rec_state + 64;
 }  // namespace snap
 
 struct DevSnapshot {
@@ -206,6 +210,7 @@ constexpr size_t off_pack = gen_pack + 2 * EG_MAX_GENS;
 constexpr size_t stride = (off_pack + 2 * EG_MAX_OFFSETS + 63) & ~size_t(63);
 static_assert(yearly % 8 == 0 && gen_cell % 2 == 0, "record alignment");
 }  // namespace rec
+namespace snap { constexpr size_t total = best_rec + rec::stride; }
 
 struct DevOut {
   uint8_t* base;
@@ -219,6 +224,7 @@ struct DevOut {
 };
 
 void set_error(const std::string& s);
+double action_cost_estimate(int action, int year_index);      // eg_tables.cpp; simulation_summary.csv "Estimated Cost"
 
 // launchers implemented in eg_rollout.hip
 struct StatsParams;
@@ -228,7 +234,9 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
                    bool helper_waves, void* ev_start, void* ev_stop);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
 int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
-int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed, void* stream);
+// `o`, n_local, first_index: the batch the own packet came from (the winner's record is kept when it is one of them)
+int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180); filled in the kernels from

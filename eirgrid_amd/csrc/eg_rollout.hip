@@ -1326,13 +1326,14 @@ __device__ void chacha12_block(const uint32_t* key, unsigned long long counter, 
 // `packets` = n_packets update packets of EG_PACKET_BYTES (one per rank, in rank order; the gathered copies when N > 1):
 // the statistics are summed here (integers: any order gives the same sum), the candidate records sit behind them.
 __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const uint8_t* packets, int n_cands, long long* zero_stats,
-                                                      unsigned long long noise_seed) {
+                                                      unsigned long long noise_seed, const uint8_t* out_base, uint32_t n_local,
+                                                      unsigned long long first_index) {
   constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
   constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
   __shared__ uint32_t s_noise[kBlocks * 16];
   __shared__ uint32_t s_key[8];
   __shared__ DevState st;
-  __shared__ int s_winner, s_improved, s_randomized_main;
+  __shared__ int s_winner, s_improved, s_randomized_main, s_owned;
   __shared__ int s_prefix[2][Y + 1];
   const int tid = threadIdx.x;
   double* pol = reinterpret_cast<double*>(snap_base + snap::pol);
@@ -1421,6 +1422,9 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
       int a = 0, b = 0;
       for (int y = 0; y < Y; ++y) { s_prefix[0][y] = a; s_prefix[1][y] = b; a += c->n_run[y]; b += c->n_def[y]; }
       s_prefix[0][Y] = a; s_prefix[1][Y] = b;
+      const long long local = c->index - (long long)first_index;
+      s_owned = (out_base && local >= 0 && local < (long long)n_local) ? 1 : 0;
+      *reinterpret_cast<uint32_t*>(snap_base + snap::best_rec_state) = s_owned ? 1u : 2u;
     } else st.stall += (uint32_t)n_ok;
     st.improved_last = improved ? 1 : 0;
   }
@@ -1441,6 +1445,13 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     }
     double* best_w = reinterpret_cast<double*>(snap_base + snap::best_w);
     for (int i = tid; i < Y * NA; i += 1024) { const int y = i / NA, a = i - y * NA; best_w[i] = pol[y * snap::kPolRow + a]; }
+    // the whole record of the winning episode (yearly rows, action list, placements) stays with the policy when the
+    // episode ran here: what the reference keeps as `best_result` for its export (multi_simulation.rs:494-508, :852-905)
+    if (s_owned) {
+      const unsigned long long* src = reinterpret_cast<const unsigned long long*>(out_base + (size_t)(c->index - (long long)first_index) * rec::stride);
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(snap_base + snap::best_rec);
+      for (int i = tid; i < (int)(rec::stride / 8); i += 1024) dst[i] = src[i];
+    }
   }
 
   // ---- apply_deficit_contrast_learning: the same factor for every episode (it depends on the stall counter only) ----
@@ -1519,9 +1530,10 @@ int launch_stalled_tables(uint8_t* d_snap, void* stream) {
   hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap);
   return (int)hipGetLastError();
 }
-int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed, void* stream) {
+int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, void* stream) {
   hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, (const uint8_t*)d_packets, n_packets,
-                     d_zero_stats, (unsigned long long)noise_seed);
+                     d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, n_local, (unsigned long long)first_index);
   return (int)hipGetLastError();
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {

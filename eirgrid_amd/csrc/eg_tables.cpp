@@ -301,4 +301,21 @@ void build_tables(const eg_world& w, HostTables& T) {
     }
 }
 
+
+// "Estimated Cost" column of simulation_summary.csv (utils/csv_export.rs:249-266 AddGenerator, :343-366 AddCarbonOffset;
+// every other action prints 0.00: the table's generator ids are empty, so the exporter's look-ups find nothing).
+// AddGenerator: calc_generator_cost(get_base_cost(year), year, can_be_urban, requires_water, requires_water) * percent / 100.
+double action_cost_estimate(int action, int year_index) {
+  if (action < 0 || year_index < 0) return 0.0;
+  if (action < kTypes * kMults) {
+    const int t = action / kMults, m = action - t * kMults;
+    const double base = kType[t].base_cost * std::pow(kType[t].rate, double(year_index));      // generator.rs:295-297
+    return price_at(base, t, year_index, location_modifier(t, true, true), kMult[m] / 100.0);
+  }
+  if (action < kTypes * kMults + kOffsetTypes * kMults) {
+    const int k = action - kTypes * kMults, o = k / kMults, m = k - o * kMults;
+    return (kOffset[o].base_cost * inflation(year_index)) * (kMult[m] / 100.0);
+  }
+  return 0.0;
+}
 }  // namespace eg

@@ -202,6 +202,14 @@ class BatchResult:
                               _p(self.n_offsets, C.c_int32), _p(self.off_pack, C.c_uint16), _p(self.n_draws, C.c_uint64),
                               _p(self.bytes_moved, C.c_double))
 
+    def export_summary_csv(self, path: str, timestamp: str = "", episode: int = 0) -> None:
+        """simulation_summary.csv (utils/csv_export.rs:215-432) of one episode of this result."""
+        one = BatchResult(*[np.ascontiguousarray(getattr(self, f)[episode:episode + 1]) for f in
+                            ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "run_log", "def_log", "act_log", "n_gens",
+                             "gen_cell", "gen_pack", "n_offsets", "off_pack", "n_draws", "bytes_moved")])
+        out = one.struct()
+        N.check(N.lib().eg_export_summary_csv(C.byref(out), path.encode(), timestamp.encode()), "eg_export_summary_csv")
+
     def lists(self, e: int, which: str):
         log = {"run": self.run_log, "def": self.def_log, "act": self.act_log}[which][e]
         cnt = {"run": self.n_run, "def": self.n_def, "act": self.n_act}[which][e]
@@ -335,6 +343,22 @@ class Engine:
     def update_stats(self, d_stats_ptr: int):
         """Reduce the last launched batch into an int64[STATS_LEN] DEVICE buffer (e.g. torch tensor .data_ptr())."""
         N.check(N.lib().eg_update_stats(self.h, C.c_void_p(d_stats_ptr)), "eg_update_stats")
+
+    def fetch_record(self, episode: int) -> BatchResult:
+        """Every output of one episode of the last batch, as a one-episode BatchResult."""
+        res = BatchResult.alloc(1)
+        out = res.struct()
+        N.check(N.lib().eg_fetch_record(self.h, episode, C.byref(out)), "eg_fetch_record")
+        return res
+
+    def fetch_best_run(self):
+        """(state, record): the record of the best episode kept by the on-device update (multi_simulation.rs:494-508 keeps
+        the best SimulationResult).  state 0 = no improvement yet, 1 = record valid, 2 = it ran on another rank."""
+        res = BatchResult.alloc(1)
+        out = res.struct()
+        state = C.c_int32(0)
+        N.check(N.lib().eg_fetch_best_run(self.h, C.byref(out), C.byref(state)), "eg_fetch_best_run")
+        return state.value, (res if state.value == 1 else None)
 
     def fetch_scores(self, n_episodes: int) -> np.ndarray:
         s = np.zeros(n_episodes)

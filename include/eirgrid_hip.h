@@ -185,6 +185,15 @@ int32_t eg_fetch_scores(eg_ctx *, double *scores);
 int32_t eg_fetch_episode_lists(eg_ctx *, uint32_t episode, double metrics[4], int32_t *n_run, uint8_t *run_log /* EG_RUN_CAP */,
                                int32_t *n_def, uint8_t *def_log /* EG_DEF_CAP */);
 
+/* Full record of ONE episode of the last batch (every non-NULL field of `out`, sized for n = 1). */
+int32_t eg_fetch_record(eg_ctx *, uint32_t episode, eg_episode_out *out);
+/* The reference keeps the SimulationResult of the best episode for its export (multi_simulation.rs:494-508, :852-905).
+ * With the policy resident on the device, k_apply_update keeps that episode's record next to the policy whenever an
+ * update installs a new best strategy.  *state: 0 = no improvement yet, 1 = `out` (n = 1) was filled, 2 = the best
+ * episode ran on another rank (ask that rank).  Yearly rows are only meaningful when the policy was pushed with
+ * eg_opts.write_yearly = 1. */
+int32_t eg_fetch_best_run(eg_ctx *, eg_episode_out *out, int32_t *state);
+
 /* Test hook: fills the LDS of every compute unit with `value` and waits.  LDS is not cleared between workgroups, so a
  * kernel that reads a word before writing it sees what the previous tenant left; the parity tests call this with small
  * integers (the values the helper protocol's sequence flags take) before a rollout. */
@@ -241,7 +250,8 @@ int32_t eg_train_step(eg_ctx *, eg_policy *, const eg_opts *opts, uint64_t seed,
  * library-owned packet (one GPU).  The update is the one of eg_policy_apply_packet, bit for bit (both evaluate
  * csrc/eg_reduced_math.h).  replay_period > 0: the episode with global index i replays the best strategy when
  * i % replay_period == 0 and a best strategy exists (decided on the device).  eg_policy_pull waits for the stream and
- * copies the policy back into `policy` (tables, best strategy, counters, improvement history). */
+ * copies the policy back into `policy` (tables, counters, the best strategy if an on-device update installed one since
+ * the push; improvement-history records are appended once per context, to whichever policy pulls first). */
 int32_t eg_policy_push(eg_ctx *, const eg_policy *, const eg_opts *opts);
 int32_t eg_device_rollout(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
                           void *d_packet);
@@ -259,6 +269,9 @@ eg_policy *eg_policy_load_json(const char *path);
 int32_t eg_policy_append_weight_history(const eg_policy *, const char *path, uint64_t iteration);
 /* improvement_history.csv of the reference's best-run export (utils/csv_export.rs:155-207); no file if there is no history */
 int32_t eg_policy_export_improvement_csv(const eg_policy *, const char *path);   /* NULL + eg_last_error() on failure */
+/* simulation_summary.csv of the best-run export (utils/csv_export.rs:215-432): final metrics, the action list with the
+ * exporter's cost estimates, the yearly summary rows.  `run` holds one episode (metrics, yearly, n_act, act_log). */
+int32_t eg_export_summary_csv(const eg_episode_out *run, const char *path, const char *timestamp);
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus

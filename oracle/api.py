@@ -111,6 +111,8 @@ def lib():
     L.og_offset_full_effect.argtypes = [C.c_int32]
     L.og_generator_cost.restype = C.c_double
     L.og_generator_cost.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.og_action_cost_estimate.restype = C.c_double
+    L.og_action_cost_estimate.argtypes = [C.c_int32, C.c_int32]
     L.og_place.restype = C.c_int32
     L.og_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
     L.og_chacha_block.argtypes = [u32p, C.c_uint64, C.c_uint64, C.c_int32, u32p]

@@ -1283,6 +1283,24 @@ double og_generator_cost(int32_t t, int32_t build_year, int32_t year, int32_t mu
   g.type = t; g.base_cost = type_base_cost(t, build_year); g.mult = clampd((double)mult_percent / 100.0, 1.0, 5.0);
   return gen_current_cost(&g, year);
 }
+/* utils/csv_export.rs:249-266 (AddGenerator) and :343-366 (AddCarbonOffset): the "Estimated Cost" column of
+ * simulation_summary.csv; every other action prints 0.00 because the table's generator ids are empty. */
+double og_action_cost_estimate(int32_t action, int32_t year) {
+  if (action >= 0 && action < 45) {
+    int t = action / 3;
+    static const int percent[3] = {100, 120, 150};
+    double base_cost = type_base_cost(t, year);
+    double accurate_cost = calc_generator_cost(t, base_cost, year, can_be_urban(t), requires_water(t), requires_water(t));
+    return accurate_cost * ((double)percent[action % 3] / 100.0);
+  }
+  if (action >= 45 && action < 57) {
+    static const double base[4] = {1000000.0, 1000000.0, 1000000000.0, 50000000.0}; /* Forest, Wetland, ActiveCapture, CarbonCredit */
+    static const int percent[3] = {100, 120, 150};
+    double adjusted_cost = base[(action - 45) / 3] * inflation_factor(year);
+    return adjusted_cost * ((double)percent[(action - 45) % 3] / 100.0);
+  }
+  return 0.0;
+}
 int32_t og_place(const og_world *w, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,
                  double *best_score) {
   map_t m; map_init(&m, w);

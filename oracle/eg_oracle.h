@@ -138,6 +138,7 @@ double og_carbon_price(int32_t year);                                           
 double og_type_power_output(int32_t type);                                           /* models/generator.rs:523-554 */
 double og_offset_full_effect(int32_t canonical_offset_type);                         /* models/carbon_offset.rs:210-233 */
 double og_generator_cost(int32_t type, int32_t build_year, int32_t year, int32_t mult_percent); /* generator.rs:582-594 */
+double og_action_cost_estimate(int32_t action, int32_t year);                         /* utils/csv_export.rs:249-266, :343-366 */
 /* placement (gpu/metal_location_search.rs:110-176) on the world's settlements at year index yi with
  * explicit extra generators; returns canonical cell or -1 */
 int32_t og_place(const og_world *, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,

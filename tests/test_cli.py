@@ -59,6 +59,16 @@ def test_training_run_checkpoints_and_resume(built, tmp_path):
     assert open(os.path.join(rd, "checkpoint_iteration.txt")).read() == "96"
     d = json.load(open(os.path.join(rd, "latest_weights.json")))
     assert d["iteration_count"] == 96 and d["best_metrics"] is not None and len(d["weights"]["2025"]) == 61
+    # best-run export (csv_export.rs:114-152): improvement history + the summary of the best episode
+    exports = os.listdir(os.path.join(rd, "enhanced_csv"))
+    assert len(exports) == 1 and re.fullmatch(r"\d{8}_\d{6}", exports[0])
+    ed = os.path.join(rd, "enhanced_csv", exports[0])
+    assert {"improvement_history.csv", "simulation_summary.csv"} <= set(os.listdir(ed))
+    summary = open(os.path.join(ed, "simulation_summary.csv"), encoding="utf-8").read().split("\n")
+    assert summary[0] == "Simulation Summary" and summary[1] == "Timestamp," + exports[0]
+    assert summary[4] == "Final Net Emissions (tonnes CO2)," + repr(d["best_metrics"]["final_net_emissions"]).rstrip("0").rstrip(".")
+    assert summary[6] == "Total Cost (\u20ac),%.2f" % d["best_metrics"]["total_cost"]
+    assert summary[-2].startswith("2050,") and summary[-27].startswith("2025,5149136,")
     # resume: the newest run directory is picked up and only the remaining iterations run
     out2 = run("--world", WORLD, "-n", "160", "--batch", "32", "--seed", "7", "-c", ck, "-r", "1000")
     assert out2.returncode == 0 and "Loaded weights from" in out2.stdout and "(96 completed, 64 remaining)" in out2.stdout

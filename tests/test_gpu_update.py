@@ -213,6 +213,7 @@ def test_device_resident_training_equals_host_updates(engine, world):
         # the same without any pull in between: the device loop is self-contained
         c = ActionWeights(); dev.push(c)
         for step in range(steps):
+            dev.debug_fill_lds((0x7FF80000, 1, 0xFFFFFFFF, 17)[step % 4])      # nothing may depend on what LDS held before
             dev.device_step(4711, step * n, n, period, 900 + step)
         dev.pull(c)
         for x, y in zip(a.tables(), c.tables()):
@@ -328,3 +329,68 @@ def test_device_resident_training_survives_pull_and_push(engine, world, tmp_path
         for rec in j.get("improvement_history") or []:
             rec.pop("timestamp", None)
     assert ja == jb
+
+
+def test_best_run_record_follows_the_best_episode(engine, world, tmp_path):
+    """The on-device update keeps the whole record of the episode that became the best strategy (the reference keeps its
+    SimulationResult for the export, multi_simulation.rs:494-508).  Shadow every step on a second engine: same policy,
+    same batch, pick the best score on the host; after an improving step the kept record must be that episode's, byte
+    for byte, and the summary CSV written from it equals the restatement's."""
+    from eirgrid_amd.engine import Engine, score_metrics
+    from oracle import csv_export as OC
+    dev = Engine(world, device=0)
+    try:
+        pol = ActionWeights(); dev.push(pol, write_yearly=True)
+        assert dev.fetch_best_run() == (0, None)
+        n, period = 96, 4
+        before = ActionWeights(); improvements = 0; expect = None
+        for step in range(16):
+            first = step * n
+            dev.pull(before)
+            mask = ((np.arange(first, first + n) % period) == 0).astype(np.uint8) if before.get("has_best_actions") == 1 else None
+            dev.device_step(515, first, n, period, 40 + step)
+            dev.pull(pol)
+            best_of = lambda p: tuple(p.get(k) for k in ("has_best", "best_net_emissions", "best_opinion", "best_cost"))
+            if best_of(pol) != best_of(before):
+                improvements += 1
+                res = engine.rollout_batch(before, 515, n, first_episode_index=first, replay_mask=mask)
+                scores = np.array([score_metrics(res.metrics[e]) if res.status[e] == 0 else -1.0 for e in range(n)])
+                expect = (res, int(np.argmax(scores)))                 # argmax returns the lowest index among ties
+            state, rec = dev.fetch_best_run()
+            if expect is None:
+                assert state == 0
+                continue
+            assert state == 1
+            res, e = expect
+            for name in ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
+                assert getattr(rec, name)[0].tobytes() == getattr(res, name)[e].tobytes(), (step, name)
+            for which in ("run", "def", "act"):
+                assert rec.lists(0, which) == res.lists(e, which)
+            g = int(res.n_gens[e])
+            assert rec.gen_cell[0, :g].tobytes() == res.gen_cell[e, :g].tobytes() and rec.gen_pack[0, :g].tobytes() == res.gen_pack[e, :g].tobytes()
+            assert rec.metrics[0].tolist() == [pol.get("best_net_emissions"), pol.get("best_opinion"), pol.get("best_cost"), pol.get("best_reliability")]
+        assert improvements >= 2
+        # a push on the same context (checkpoint / resume) keeps the record; the export reads it
+        dev.push(pol, write_yearly=True)
+        state, rec = dev.fetch_best_run()
+        assert state == 1
+        path = tmp_path / "simulation_summary.csv"
+        rec.export_summary_csv(str(path), "stamp")
+        assert path.read_bytes().decode() == OC.summary_csv_text(rec.metrics[0], rec.yearly[0], rec.n_act[0], rec.act_log[0], "stamp")
+        assert rec.yearly[0, 25, 0] == 2050.0 and rec.yearly[0, 0, 1] > 5e6
+        # a winner that ran in another rank's shard: this context only knows about its own last batch
+        PB = N.PACKET_BYTES
+        packets = torch.zeros(2 * PB, dtype=torch.uint8, device="cuda")
+        fresh = Engine(world, device=0)
+        try:
+            fresh.push(ActionWeights())
+            for r in range(2):
+                fresh.device_rollout(31, r * n, n, 0, packets.data_ptr() + r * PB)
+            cand = [packets[r * PB + 8 * N.STATS_LEN:r * PB + 8 * N.STATS_LEN + 16].cpu().numpy().view(np.float64)[0] for r in range(2)]
+            fresh.device_apply(packets.data_ptr(), 2, packets.data_ptr(), 1)
+            state, rec = fresh.fetch_best_run()
+            assert state == (2 if cand[0] >= cand[1] else 1)
+        finally:
+            fresh.close()
+    finally:
+        dev.close()
