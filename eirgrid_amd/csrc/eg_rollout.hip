@@ -35,6 +35,7 @@ namespace eg {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kD2Max = 144, kD2Stride = 146;   // factor table by squared cell distance: 0..144 (12 km = the largest radius), padded
 constexpr int kCmdYear = 1 << 30;       // helper command: fold next year's starting sums (else: a placement search)
 constexpr int kHelperWaves = 1;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
 constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
@@ -57,7 +58,7 @@ __device__ __forceinline__ int deficit_slot_of(int action) {
 }
 
 struct __align__(16) Smem {
-  double dr[kRadiusClasses * 169];    // d/R by (|di|, |dj|) for every radius class; 1.0 where d >= R
+  double dr[kRadiusClasses * kD2Stride];   // d/R by squared cell distance min(di^2 + dj^2, 144) for every radius class; 1.0 where d >= R
   double scaled[64];                  // stalled sampler: weights^p in sorted order
   double type_out[16];                // per generator type: output of an operational new plant
   double type_co2[16];                //                     CO2
@@ -226,8 +227,15 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 }
 
 // small per-type / per-class tables -> LDS (one dependent LDS read instead of chains of L2 round trips)
+// The host table is indexed by (|di|, |dj|) <= 12; the distance, hence the factor, only depends on di^2 + dj^2 (grid
+// coordinates are whole kilometres, so dx^2 + dy^2 is exact), and the kernels index by that: one dot product instead of
+// two absolute values, two clamps and a linearisation.  Sums that are not a sum of two squares are never read.
 __device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) {
-  for (int i = lane; i < kRadiusClasses * 169; i += kWave) sm.dr[i] = T.dr()[i];
+  for (int i = lane; i < kRadiusClasses * kD2Stride; i += kWave) sm.dr[i] = 1.0;
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
+    const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
+    if (q <= kD2Max) sm.dr[rc * kD2Stride + q] = T.dr()[i];
+  }
 }
 __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane, bool with_factors) {
   if (with_factors) load_factor_table(T, lane);
@@ -323,16 +331,14 @@ __device__ __noinline__ int weighted_pick(int table_offset, int n, double u, int
 }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
-// byte offset of a factor inside the workgroup's LDS block: base (the 13x13 table of the radius class) +
-// (min(|ci - gi|, 12) * 13 + min(|cj - gj|, 12)) * 8 — packed 16-bit arithmetic and one dot product that accumulates onto
-// the base
-__device__ __forceinline__ int penalty_offset(short2v cpk, int gen_packed, int base) {
+// factor of one generator for this lane's candidate: (ci - gi, cj - gj) as two int16, their squared length by one dot
+// product, capped at 144 (12 km, the largest radius: the table holds 1.0 there)
+__device__ __forceinline__ double factor_at(short2v cpk, int gen_packed, int table_offset) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
-  short2v d = cpk - g;
-  const short2v cap = {12, 12}, stride = {13 * 8, 8};
-  d = __builtin_elementwise_max(d, g - cpk);
-  d = __builtin_elementwise_min(d, cap);
-  return __builtin_amdgcn_sdot2(d, stride, base, false);
+  const short2v d = cpk - g;
+  int q = __builtin_amdgcn_sdot2(d, d, 0, false);
+  q = q < kD2Max ? q : kD2Max;
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + (table_offset + q * 8));
 }
 
 // A search multiplies te by the factor of every generator, in list order.  Searches of the same (year, variant) revisit
@@ -347,25 +353,32 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
   double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
   const int dr_off = (int)(reinterpret_cast<const char*>(dr) - reinterpret_cast<const char*>(&sm));   // table base inside the LDS block
-  for (int gb = k0; gb < ngen_s; gb += kWave) {                   // generators in list order
-    // Lanes beyond the list hold a generator far off the grid: every |d| clamps to 12, where the factor table is 1.0.
+  const int k0_s = __builtin_amdgcn_readfirstlane(k0);           // uniform (it comes out of a per-wave cache): scalar loop control
+  for (int gb = k0_s; gb < ngen_s; gb += kWave) {                 // generators in list order
+    // Lanes beyond the list hold a generator far off the grid: its squared distance caps at 144, where the table is 1.0.
     const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
     const int mi = mine / kGrid;
     const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
     const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-    // Branch-free: the factor table holds 1.0 wherever d >= R (including every |di| or |dj| = 12), and x * 1.0 == x
+    // Branch-free: the factor table holds 1.0 wherever d >= R (including the cap), and x * 1.0 == x
     // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
     // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
     // current four are multiplied in list order (only the multiplies form a chain).
-#define EG_FACTOR(j) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + penalty_offset(cpk, __builtin_amdgcn_readlane(mp, (j)), dr_off)))
-    double f0 = EG_FACTOR(0), f1 = EG_FACTOR(1), f2 = EG_FACTOR(2), f3 = EG_FACTOR(3);
-    for (int j = 4; j < cnt; j += 4) {
-      const double g0 = EG_FACTOR(j), g1 = EG_FACTOR(j + 1), g2 = EG_FACTOR(j + 2), g3 = EG_FACTOR(j + 3);
+#define EG_FACTOR(j) factor_at(cpk, __builtin_amdgcn_readlane(mp, (j)), dr_off)
+    // two register sets take turns, so nothing is copied between trips
+    double a0 = EG_FACTOR(0), a1 = EG_FACTOR(1), a2 = EG_FACTOR(2), a3 = EG_FACTOR(3);
+    for (int j = 4;;) {
+      if (j >= cnt) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; break; }
+      const double b0 = EG_FACTOR(j), b1 = EG_FACTOR(j + 1), b2 = EG_FACTOR(j + 2), b3 = EG_FACTOR(j + 3);
       __builtin_amdgcn_sched_barrier(0);      // keep the four LDS reads in flight ahead of the multiply chain
-      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
-      f0 = g0; f1 = g1; f2 = g2; f3 = g3;
+      s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+      j += 4;
+      if (j >= cnt) { s = s * b0; s = s * b1; s = s * b2; s = s * b3; break; }
+      a0 = EG_FACTOR(j); a1 = EG_FACTOR(j + 1); a2 = EG_FACTOR(j + 2); a3 = EG_FACTOR(j + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+      j += 4;
     }
-    s = s * f0; s = s * f1; s = s * f2; s = s * f3;
 #undef EG_FACTOR
   }
   return s;
@@ -539,7 +552,7 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long th1 = __builtin_readcyclecounter();
 #endif
-    const double s = chunk_score(sm.dr + rc * 169, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v);
+    const double s = chunk_score(sm.dr + rc * kD2Stride, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v);
 #ifdef EG_STAMPS
     const unsigned long long th2 = __builtin_readcyclecounter();
 #endif
@@ -560,7 +573,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   const int info = __builtin_amdgcn_readfirstlane(sm.type_info[type]);      // uniform: list address arithmetic on the scalar unit
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
-  const double* dr = sm.dr + rc * 169;
+  const double* dr = sm.dr + rc * kD2Stride;
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
@@ -589,6 +602,9 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 #endif
     const ChunkBest b0 = chunk_reduce(s0, (int)c.cell, c.m03);
     if (b0.score > 0.0) { best = b0.score; best_c = b0.cell; m03w = b0.m03; }
+    // the records of the first chunk the episode wave would evaluate itself are requested before it waits for the
+    // helper: when chunk 1 is needed, that chunk usually is as well
+    c = list[(kHelpers + 1) * kWave + lane];
     for (int h = 1; h <= kHelpers && more; ++h) {
       if (!(readlane_f64(bound, h - 1) >= best)) { more = false; break; }
 #ifdef EG_STAMPS
@@ -607,7 +623,6 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     }
     if (more && !(readlane_f64(bound, kHelpers) >= best)) more = false;
     first = kHelpers + 1;
-    if (more) c = list[first * kWave + lane];
 #ifdef EG_STAMPS
     if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
 #endif

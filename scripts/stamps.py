@@ -31,3 +31,14 @@ k = int(np.argmax(st[:, 7]))
 nm = st[:, 30].sum()
 print(f"  helper results merged/ep {st[:, 30].mean():.1f}: episode wave spun {st[:, 6].sum() / nm:.0f} cyc per merge; helper per chunk: load wait {st[:, 27].sum() / nm:.0f}, score {st[:, 28].sum() / nm:.0f}, reduce {st[:, 29].sum() / nm:.0f}")
 print(f"  slowest episode {k}: total {st[k, 7]:.0f}, placement {st[k, 1]:.0f}, searches {st[k, 11]:.0f}, chunks {st[k, 8]:.0f}, gens {res.n_gens[k]}, year-start {st[k, 0]:.0f}, sampling {st[k, 2]:.0f}")
+
+# the launch lasts as long as its slowest episode: the same table for the slowest 1 % of the batch
+order = np.argsort(st[:, 7])[::-1][:max(1, B // 100)]
+sl = st[order]
+tot = sl[:, 7].mean()
+print(f"slowest {len(order)} episodes: mean cycles {tot:.0f}, gens {res.n_gens[order].mean():.1f}, searches {sl[:, 11].mean():.1f}, chunks/search {sl[:, 8].sum() / sl[:, 11].sum():.2f}, "
+      f"actions logged {res.n_act[order].sum(axis=1).mean():.1f} sampled + {res.n_def[order].sum(axis=1).mean():.1f} repair")
+for i, n in names.items():
+    v = sl[:, i].mean()
+    if v / tot >= 0.01: print(f"  {n:34s} {v:10.0f} cycles  {100 * v / tot:5.1f} %")
+print(f"  placement detail: generator loop {sl[:, 9].mean():.0f} cyc/ep ({sl[:, 9].sum() / sl[:, 8].sum():.0f}/chunk)  reduce+select {sl[:, 10].mean():.0f} cyc/ep  rest {(sl[:, 1] - sl[:, 9] - sl[:, 10]).mean():.0f} cyc/ep; per search {sl[:, 1].sum() / sl[:, 11].sum():.0f}")
