@@ -59,6 +59,8 @@ __device__ __forceinline__ int deficit_slot_of(int action) {
 
 struct __align__(16) Smem {
   double dr[kRadiusClasses * kD2Stride];   // d/R by squared cell distance min(di^2 + dj^2, 144) for every radius class; 1.0 where d >= R
+  int gstage[2][kWave + 8];           // per wave: (gi, gj) as two int16 of the 64 generators being folded (read back four at a time);
+                                      // the tail stays at the off-grid padding value: the pipeline reads up to three groups ahead
   double scaled[64];                  // stalled sampler: weights^p in sorted order
   double type_out[16];                // per generator type: output of an operational new plant
   double type_co2[16];                //                     CO2
@@ -85,7 +87,11 @@ struct __align__(16) Smem {
   unsigned long long hdbg[2][4];
 #endif
 };
-static_assert(sizeof(Smem) <= 163840 / 12, "twelve episodes per CU: the same limit as three waves per SIMD");
+// gfx950 hands out LDS in granules of 1280 bytes (160 KB / 128): ten granules per episode is what lets twelve workgroups
+// share a CU, the same limit as three waves per SIMD.  One byte more costs a twelfth of the throughput kernel.
+#ifndef EG_STAMPS
+static_assert(sizeof(Smem) <= 10 * 1280, "twelve episodes per CU");
+#endif
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
@@ -231,6 +237,8 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 // coordinates are whole kilometres, so dx^2 + dy^2 is exact), and the kernels index by that: one dot product instead of
 // two absolute values, two clamps and a linearisation.  Sums that are not a sum of two squares are never read.
 __device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) {
+  // tails of the staging rows of chunk_product: generators far off the grid (their factor is 1.0), never overwritten
+  if (lane < 8) { sm.gstage[0][kWave + lane] = (int)0xC000C000; sm.gstage[1][kWave + lane] = (int)0xC000C000; }
   for (int i = lane; i < kRadiusClasses * kD2Stride; i += kWave) sm.dr[i] = 1.0;
   for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
     const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
@@ -347,54 +355,107 @@ __device__ __forceinline__ double factor_at(short2v cpk, int gen_packed, int tab
 // the same order, hence the same bits.  (Years with many additions — the slow episodes — mostly repeat one variant.)
 struct PrefixCache { double product; int key; int count; };      // key: year << 8 | variant, -1 = empty; count: generators folded in
 
-// s_init times the factors of generators [k0, ngen_s) for this lane's candidate cell
-__device__ __forceinline__ double chunk_product(const double* dr, int lane, int k0, int ngen_s, double s_init, int cell) {
+// s_init times the factors of generators [k0, ngen_s) for this lane's candidate cell.  `stage`: 0 on the episode wave, 1 on
+// the helper wave (each wave has its own staging row in LDS).
+// A lone wave issues one instruction per turn of its SIMD whatever the instruction is, so the loop is written for the
+// fewest instructions per generator: the packed coordinates of 64 generators are staged in LDS once and come back four
+// at a time as ONE broadcast 128-bit read (instead of a readlane and a lane-index add each); per generator that leaves a
+// packed subtract, the dot product, the cap, the address, the table read and the multiply.
+template <bool kLatency>
+__device__ __forceinline__ double chunk_product(const double* dr, int lane, int k0, int ngen_s, double s_init, int cell, int stage) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
   const int dr_off = (int)(reinterpret_cast<const char*>(dr) - reinterpret_cast<const char*>(&sm));   // table base inside the LDS block
+  int* row = sm.gstage[stage];
+  const int4* row4 = reinterpret_cast<const int4*>(row);
   const int k0_s = __builtin_amdgcn_readfirstlane(k0);           // uniform (it comes out of a per-wave cache): scalar loop control
   for (int gb = k0_s; gb < ngen_s; gb += kWave) {                 // generators in list order
     // Lanes beyond the list hold a generator far off the grid: its squared distance caps at 144, where the table is 1.0.
     const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
     const int mi = mine / kGrid;
     const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
+    row[lane] = mp;
+    asm volatile("" ::: "memory");      // LDS executes a wave's accesses in program order: only the compiler must keep it
     const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-    // Branch-free: the factor table holds 1.0 wherever d >= R (including the cap), and x * 1.0 == x
-    // exactly, so out-of-range generators (and the padding up to a multiple of four) multiply by 1.0 instead of
-    // branching.  Four generators per trip, software-pipelined: the next four factors are fetched from LDS while the
-    // current four are multiplied in list order (only the multiplies form a chain).
-#define EG_FACTOR(j) factor_at(cpk, __builtin_amdgcn_readlane(mp, (j)), dr_off)
-    // two register sets take turns, so nothing is copied between trips
-    double a0 = EG_FACTOR(0), a1 = EG_FACTOR(1), a2 = EG_FACTOR(2), a3 = EG_FACTOR(3);
-    for (int j = 4;;) {
-      if (j >= cnt) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; break; }
-      const double b0 = EG_FACTOR(j), b1 = EG_FACTOR(j + 1), b2 = EG_FACTOR(j + 2), b3 = EG_FACTOR(j + 3);
-      __builtin_amdgcn_sched_barrier(0);      // keep the four LDS reads in flight ahead of the multiply chain
-      s = s * a0; s = s * a1; s = s * a2; s = s * a3;
-      j += 4;
-      if (j >= cnt) { s = s * b0; s = s * b1; s = s * b2; s = s * b3; break; }
-      a0 = EG_FACTOR(j); a1 = EG_FACTOR(j + 1); a2 = EG_FACTOR(j + 2); a3 = EG_FACTOR(j + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      s = s * b0; s = s * b1; s = s * b2; s = s * b3;
-      j += 4;
+    // Branch-free: the factor table holds 1.0 wherever d >= R (including the cap), and x * 1.0 == x exactly, so
+    // out-of-range generators and the padding (up to a multiple of eight, plus the group the pipeline runs ahead) multiply
+    // by 1.0 instead of branching.  Software-pipelined: while four factors are multiplied in list order (only the
+    // multiplies form a chain) the next four are on their way from the table, and the packed coordinates of the group
+    // after that from the staging row; two register sets take turns inside one straight-line loop body.  The four
+    // generators of a group go through each step together, which keeps dependent instructions apart without wait states.
+#define EG_FACTORS(g4, f0, f1, f2, f3) { \
+      short2v e0, e1, e2, e3; int q0, q1, q2, q3; \
+      { short2v t; __builtin_memcpy(&t, &g4.x, 4); e0 = cpk - t; __builtin_memcpy(&t, &g4.y, 4); e1 = cpk - t; \
+        __builtin_memcpy(&t, &g4.z, 4); e2 = cpk - t; __builtin_memcpy(&t, &g4.w, 4); e3 = cpk - t; } \
+      __builtin_amdgcn_sched_barrier(0); \
+      q0 = __builtin_amdgcn_sdot2(e0, e0, 0, false); q1 = __builtin_amdgcn_sdot2(e1, e1, 0, false); \
+      q2 = __builtin_amdgcn_sdot2(e2, e2, 0, false); q3 = __builtin_amdgcn_sdot2(e3, e3, 0, false); \
+      __builtin_amdgcn_sched_barrier(0); \
+      q0 = q0 < kD2Max ? q0 : kD2Max; q1 = q1 < kD2Max ? q1 : kD2Max; q2 = q2 < kD2Max ? q2 : kD2Max; q3 = q3 < kD2Max ? q3 : kD2Max; \
+      __builtin_amdgcn_sched_barrier(0); \
+      f0 = *reinterpret_cast<const double*>(lds0 + (dr_off + q0 * 8)); f1 = *reinterpret_cast<const double*>(lds0 + (dr_off + q1 * 8)); \
+      f2 = *reinterpret_cast<const double*>(lds0 + (dr_off + q2 * 8)); f3 = *reinterpret_cast<const double*>(lds0 + (dr_off + q3 * 8)); }
+#define EG_FACTORS_LOOSE(g4, f0, f1, f2, f3) { f0 = factor_at(cpk, g4.x, dr_off); f1 = factor_at(cpk, g4.y, dr_off); \
+                                               f2 = factor_at(cpk, g4.z, dr_off); f3 = factor_at(cpk, g4.w, dr_off); }
+    const char* lds0 = reinterpret_cast<const char*>(&sm);
+    double a0, a1, a2, a3, b0, b1, b2, b3;
+    const int groups = (cnt + 3) >> 2;
+    if constexpr (kLatency) {
+      // small-batch kernel: one straight-line loop body of two groups (padding groups multiply by 1.0; the last trip
+      // fetches one group it never multiplies) — no exits inside, so the wait counts stay exact
+      const int pairs = (groups + 1) >> 1;
+      int4 ga = row4[0], gb4 = row4[1];
+      EG_FACTORS(ga, a0, a1, a2, a3)
+      for (int p = 0; p < pairs; ++p) {
+        ga = row4[2 * p + 2];
+        EG_FACTORS(gb4, b0, b1, b2, b3)
+        __builtin_amdgcn_sched_barrier(0);      // the four table reads stay in flight ahead of the multiply chain
+        s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+        gb4 = row4[2 * p + 3];
+        EG_FACTORS(ga, a0, a1, a2, a3)
+        __builtin_amdgcn_sched_barrier(0);
+        s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+      }
+    } else {
+      // throughput kernel: exactly the groups the list needs
+      int4 gc = row4[0], gn = row4[1];
+      EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
+      for (int k = 1;;) {
+        if (k >= groups) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; break; }
+        gc = gn; gn = row4[k + 1];
+        EG_FACTORS_LOOSE(gc, b0, b1, b2, b3)
+        __builtin_amdgcn_sched_barrier(0);
+        s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+        ++k;
+        if (k >= groups) { s = s * b0; s = s * b1; s = s * b2; s = s * b3; break; }
+        gc = gn; gn = row4[k + 1];
+        EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
+        __builtin_amdgcn_sched_barrier(0);
+        s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+        ++k;
+      }
     }
-#undef EG_FACTOR
+#undef EG_FACTORS_LOOSE
+#undef EG_FACTORS
+    asm volatile("" ::: "memory");
   }
   return s;
 }
 // Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
+template <bool kLatency>
 __device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
                                               double cf, int cell) {
-  const double s = (chunk_product(dr, lane, 0, ngen_s, te, cell) * cf) * size_factor;
+  const double s = (chunk_product<kLatency>(dr, lane, 0, ngen_s, te, cell, 0) * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
 // ... continuing the product kept from the last search of the same (year, variant) when there is one
+template <bool kLatency>
 __device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
-                                              double cf, int cell, PrefixCache& cache, int key) {
+                                              double cf, int cell, PrefixCache& cache, int key, int stage) {
   double s = te; int k0 = 0;
   if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
-  s = chunk_product(dr, lane, k0, ngen_s, s, cell);
+  s = chunk_product<kLatency>(dr, lane, k0, ngen_s, s, cell, stage);
   cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
   return r < kCells ? s : 0.0;
@@ -402,9 +463,22 @@ __device__ __forceinline__ double chunk_score(const double* dr, double size_fact
 
 struct ChunkBest { double score, m03; int cell; };
 // maximum of a chunk's scores, ties to the lowest cell, with the winner's 0.03 * mean settlement opinion
+template <bool kLatency>
 __device__ __forceinline__ ChunkBest chunk_reduce(double s, int cell, double m03) {
   ChunkBest b;
-  b.score = wave_max_f64(s);
+  // Scores are not negative, so their order is the order of their bit patterns.  Almost always a single lane holds the
+  // largest high word: that lane is the winner and nothing else has to be reduced (small-batch kernel: fewer
+  // instructions on the critical path; the throughput kernel keeps the branch-free form).
+  const unsigned hi = (unsigned)__double2hiint(s);
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned long long top = __ballot(hi == mh);
+  if (kLatency && __popcll(top) == 1) {
+    const int w = __ffsll((long long)top) - 1;
+    b.score = readlane_f64(s, w); b.cell = __builtin_amdgcn_readlane(cell, w); b.m03 = readlane_f64(m03, w);
+    return b;
+  }
+  const unsigned ml = wave_max_u32(hi == mh ? (unsigned)__double2loint(s) : 0u);
+  b.score = __hiloint2double((int)mh, (int)ml);
   int win_c = s == b.score ? cell : kCells;
   const unsigned long long holders = __ballot(s == b.score);
   if (__popcll(holders) == 1) win_c = __builtin_amdgcn_readlane(cell, __ffsll((long long)holders) - 1);
@@ -552,11 +626,11 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long th1 = __builtin_readcyclecounter();
 #endif
-    const double s = chunk_score(sm.dr + rc * kD2Stride, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v);
+    const double s = chunk_score<true>(sm.dr + rc * kD2Stride, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v, 1);
 #ifdef EG_STAMPS
     const unsigned long long th2 = __builtin_readcyclecounter();
 #endif
-    const ChunkBest b = chunk_reduce(s, (int)c.cell, c.m03);
+    const ChunkBest b = chunk_reduce<true>(s, (int)c.cell, c.m03);
 #ifdef EG_STAMPS
     if (lane == 0) { sm.hdbg[h - 1][0] = th1 - th0; sm.hdbg[h - 1][1] = th2 - th1; sm.hdbg[h - 1][2] = __builtin_readcyclecounter() - th2; }
 #endif
@@ -595,12 +669,12 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-    const double s0 = chunk_score(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell, cache0, (yi << 8) | v);
+    const double s0 = chunk_score<true>(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell, cache0, (yi << 8) | v, 0);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
 #endif
-    const ChunkBest b0 = chunk_reduce(s0, (int)c.cell, c.m03);
+    const ChunkBest b0 = chunk_reduce<true>(s0, (int)c.cell, c.m03);
     if (b0.score > 0.0) { best = b0.score; best_c = b0.cell; m03w = b0.m03; }
     // the records of the first chunk the episode wave would evaluate itself are requested before it waits for the
     // helper: when chunk 1 is needed, that chunk usually is as well
@@ -640,13 +714,13 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     // the single-wave kernel keeps the products of chunks 0 and 1, the episode wave of the helper kernel that of chunk 0
     // (the kept products are used by the small-batch kernel only: in the throughput kernel the extra live registers cost
     //  more than the shorter loops give back)
-    const double s = chunk_score(dr, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur);
+    const double s = chunk_score<(kHelpers > 0)>(dr, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
 #endif
     if (__any(s > best || (s == best && s > 0.0 && cell_cur < best_c))) {
-      const ChunkBest b = chunk_reduce(s, cell_cur, m03_cur);
+      const ChunkBest b = chunk_reduce<(kHelpers > 0)>(s, cell_cur, m03_cur);
       if (b.score > best || (b.score == best && b.cell < best_c)) { best = b.score; best_c = b.cell; m03w = b.m03; }
     }
 #ifdef EG_STAMPS
