@@ -185,6 +185,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         for (int r = 0; r < kPsStride; ++r) { list[r].te = 0.0; list[r].cf = 1.0; list[r].m03 = 0.0; list[r].cell = 0; list[r].pad = 0; }
         for (int r = 0; r < kCells; ++r) {
           list[r].te = te[order[r]]; list[r].cf = marine ? H.coastf[order[r]] : 1.0; list[r].m03 = H.m03[order[r]]; list[r].cell = uint32_t(order[r]);
+          list[r].pad = uint32_t(4 * (order[r] / kGrid)) | (uint32_t(4 * (order[r] % kGrid)) << 16);
         }
       }
   }

@@ -63,7 +63,7 @@ void build_tables(const eg_world& w, HostTables& t);
 #endif
 
 // One entry of a sorted candidate list: everything the placement search reads about a candidate, 32 bytes.
-struct PsRec { double te, cf, m03; uint32_t cell, pad; };
+struct PsRec { double te, cf, m03; uint32_t cell, pad; };   // pad: the cell's grid coordinates times four, 4 i | 4 j << 16 (small-batch kernel)
 static_assert(sizeof(PsRec) == 32, "candidate record");
 
 // Device tables: ONE allocation, fixed layout.  A kernel receives a single base pointer and addresses every table at a

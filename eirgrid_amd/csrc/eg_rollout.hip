@@ -95,6 +95,13 @@ static_assert(sizeof(Smem) <= 10 * 1280, "twelve episodes per CU");
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
 __shared__ Smem sm;
+// Extra LDS of the small-batch kernel only (it is not referenced by the throughput kernel, so it costs that one nothing).
+struct __align__(16) SmemLatency {
+  int gpk[EG_MAX_GENS + 16];                        // (4 gi, 4 gj) as two int16 per generator of the episode; padding beyond the list
+  double dr16[kRadiusClasses * kD2Stride * 2];      // the factor table at a stride of 16 bytes (see chunk_product_latency)
+};
+__shared__ SmemLatency sl;
+constexpr int kGenPad4 = (int)0xE000E000;           // a generator far off the grid, in the x4 coordinates
 #define SM_W (sm.pol)                      // main weights [61]
 #define SM_DW (sm.pol + snap::kPolDw)      // deficit weights [15]
 #define SM_CW (sm.pol + snap::kPolCw)      // action-count weights [21]
@@ -245,6 +252,15 @@ __device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) 
     if (q <= kD2Max) sm.dr[rc * kD2Stride + q] = T.dr()[i];
   }
 }
+// small-batch kernel: the generator list starts as padding everywhere; the factor table goes in at a stride of 16 bytes
+__device__ __forceinline__ void load_latency_tables(const DevTables& T, int lane) {
+  for (int i = lane; i < EG_MAX_GENS + 16; i += kWave) sl.gpk[i] = kGenPad4;
+  for (int i = lane; i < kRadiusClasses * kD2Stride; i += kWave) sl.dr16[2 * i] = 1.0;
+  for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
+    const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
+    if (q <= kD2Max) sl.dr16[2 * (rc * kD2Stride + q)] = T.dr()[i];
+  }
+}
 __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane, bool with_factors) {
   if (with_factors) load_factor_table(T, lane);
   if (lane < kTypes) {
@@ -361,7 +377,10 @@ struct PrefixCache { double product; int key; int count; };      // key: year <<
 // fewest instructions per generator: the packed coordinates of 64 generators are staged in LDS once and come back four
 // at a time as ONE broadcast 128-bit read (instead of a readlane and a lane-index add each); per generator that leaves a
 // packed subtract, the dot product, the cap, the address, the table read and the multiply.
-template <bool kLatency>
+// Throughput kernel (one wave per episode, twelve episodes per CU).  `stage`: the wave's staging row in LDS.
+// The packed coordinates of 64 generators are staged in LDS once and come back four at a time as ONE broadcast 128-bit
+// read (instead of a readlane and a lane-index add each); per generator that leaves a packed subtract, the dot product,
+// the cap, the address, the table read and the multiply.
 __device__ __forceinline__ double chunk_product(const double* dr, int lane, int k0, int ngen_s, double s_init, int cell, int stage) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   double s = s_init;
@@ -378,84 +397,109 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
     row[lane] = mp;
     asm volatile("" ::: "memory");      // LDS executes a wave's accesses in program order: only the compiler must keep it
     const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+    const int groups = (cnt + 3) >> 2;
     // Branch-free: the factor table holds 1.0 wherever d >= R (including the cap), and x * 1.0 == x exactly, so
-    // out-of-range generators and the padding (up to a multiple of eight, plus the group the pipeline runs ahead) multiply
-    // by 1.0 instead of branching.  Software-pipelined: while four factors are multiplied in list order (only the
-    // multiplies form a chain) the next four are on their way from the table, and the packed coordinates of the group
-    // after that from the staging row; two register sets take turns inside one straight-line loop body.  The four
-    // generators of a group go through each step together, which keeps dependent instructions apart without wait states.
-#define EG_FACTORS(g4, f0, f1, f2, f3) { \
-      short2v e0, e1, e2, e3; int q0, q1, q2, q3; \
-      { short2v t; __builtin_memcpy(&t, &g4.x, 4); e0 = cpk - t; __builtin_memcpy(&t, &g4.y, 4); e1 = cpk - t; \
-        __builtin_memcpy(&t, &g4.z, 4); e2 = cpk - t; __builtin_memcpy(&t, &g4.w, 4); e3 = cpk - t; } \
-      __builtin_amdgcn_sched_barrier(0); \
-      q0 = __builtin_amdgcn_sdot2(e0, e0, 0, false); q1 = __builtin_amdgcn_sdot2(e1, e1, 0, false); \
-      q2 = __builtin_amdgcn_sdot2(e2, e2, 0, false); q3 = __builtin_amdgcn_sdot2(e3, e3, 0, false); \
-      __builtin_amdgcn_sched_barrier(0); \
-      q0 = q0 < kD2Max ? q0 : kD2Max; q1 = q1 < kD2Max ? q1 : kD2Max; q2 = q2 < kD2Max ? q2 : kD2Max; q3 = q3 < kD2Max ? q3 : kD2Max; \
-      __builtin_amdgcn_sched_barrier(0); \
-      f0 = *reinterpret_cast<const double*>(lds0 + (dr_off + q0 * 8)); f1 = *reinterpret_cast<const double*>(lds0 + (dr_off + q1 * 8)); \
-      f2 = *reinterpret_cast<const double*>(lds0 + (dr_off + q2 * 8)); f3 = *reinterpret_cast<const double*>(lds0 + (dr_off + q3 * 8)); }
+    // out-of-range generators and the padding up to a multiple of four multiply by 1.0 instead of branching.
+    // Software-pipelined: while four factors are multiplied in list order (only the multiplies form a chain) the next
+    // four are on their way from the table; two register sets take turns.
 #define EG_FACTORS_LOOSE(g4, f0, f1, f2, f3) { f0 = factor_at(cpk, g4.x, dr_off); f1 = factor_at(cpk, g4.y, dr_off); \
                                                f2 = factor_at(cpk, g4.z, dr_off); f3 = factor_at(cpk, g4.w, dr_off); }
-    const char* lds0 = reinterpret_cast<const char*>(&sm);
     double a0, a1, a2, a3, b0, b1, b2, b3;
-    const int groups = (cnt + 3) >> 2;
-    if constexpr (kLatency) {
-      // small-batch kernel: one straight-line loop body of two groups (padding groups multiply by 1.0; the last trip
-      // fetches one group it never multiplies) — no exits inside, so the wait counts stay exact
-      const int pairs = (groups + 1) >> 1;
-      int4 ga = row4[0], gb4 = row4[1];
-      EG_FACTORS(ga, a0, a1, a2, a3)
-      for (int p = 0; p < pairs; ++p) {
-        ga = row4[2 * p + 2];
-        EG_FACTORS(gb4, b0, b1, b2, b3)
-        __builtin_amdgcn_sched_barrier(0);      // the four table reads stay in flight ahead of the multiply chain
-        s = s * a0; s = s * a1; s = s * a2; s = s * a3;
-        gb4 = row4[2 * p + 3];
-        EG_FACTORS(ga, a0, a1, a2, a3)
-        __builtin_amdgcn_sched_barrier(0);
-        s = s * b0; s = s * b1; s = s * b2; s = s * b3;
-      }
-    } else {
-      // throughput kernel: exactly the groups the list needs
-      int4 gc = row4[0], gn = row4[1];
+    int4 gc = row4[0], gn = row4[1];
+    EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
+    for (int k = 1;;) {
+      if (k >= groups) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; break; }
+      gc = gn; gn = row4[k + 1];
+      EG_FACTORS_LOOSE(gc, b0, b1, b2, b3)
+      __builtin_amdgcn_sched_barrier(0);
+      s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+      ++k;
+      if (k >= groups) { s = s * b0; s = s * b1; s = s * b2; s = s * b3; break; }
+      gc = gn; gn = row4[k + 1];
       EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
-      for (int k = 1;;) {
-        if (k >= groups) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; break; }
-        gc = gn; gn = row4[k + 1];
-        EG_FACTORS_LOOSE(gc, b0, b1, b2, b3)
-        __builtin_amdgcn_sched_barrier(0);
-        s = s * a0; s = s * a1; s = s * a2; s = s * a3;
-        ++k;
-        if (k >= groups) { s = s * b0; s = s * b1; s = s * b2; s = s * b3; break; }
-        gc = gn; gn = row4[k + 1];
-        EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
-        __builtin_amdgcn_sched_barrier(0);
-        s = s * b0; s = s * b1; s = s * b2; s = s * b3;
-        ++k;
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+      ++k;
     }
 #undef EG_FACTORS_LOOSE
-#undef EG_FACTORS
     asm volatile("" ::: "memory");
   }
   return s;
 }
+
+// Small-batch kernel (an episode wave and a helper wave per episode, at most four episodes per CU).  A lone wave issues
+// one instruction per turn of its SIMD whatever the instruction is, so this version is written for the fewest
+// instructions per generator, and spends LDS (plentiful at four workgroups per CU) to get there:
+//  * the packed coordinates of the episode's generators live in LDS (sl.gpk, appended when a generator is placed, both
+//    waves read it): no staging, no cell -> (i, j) division per search, four generators per broadcast 128-bit read;
+//  * coordinates are kept times four and the factor table has a stride of 16 bytes, so the dot product of the packed
+//    difference with itself, accumulated onto the table's address, IS the address of the factor: per generator a packed
+//    subtract, the accumulator move, the dot product, the cap, the table read and the multiply;
+//  * one straight-line loop body of two groups, so the wait counts stay exact; padding multiplies by 1.0.
+// k0: generators [0, k0) are already in s_init (kept product); the first group is masked accordingly.
+__device__ __forceinline__ double chunk_product_latency(int class_off, int k0, int ngen_s, double s_init, int xy4) {
+  short2v cpk; __builtin_memcpy(&cpk, &xy4, 4);
+  double s = s_init;
+  const int k0_s = __builtin_amdgcn_readfirstlane(k0);
+  const int g0 = k0_s >> 2, skip = k0_s & 3;
+  const int groups = ((ngen_s + 3) >> 2) - g0;
+  if (groups <= 0) return s;
+  const int4* row4 = reinterpret_cast<const int4*>(sl.gpk) + g0;
+  const char* t0 = reinterpret_cast<const char*>(sl.dr16);
+  const int cap = class_off + 16 * kD2Max;
+#define EG_FACTORS(g4, f0, f1, f2, f3) { \
+    short2v e0, e1, e2, e3; int q0, q1, q2, q3; \
+    { short2v t; __builtin_memcpy(&t, &g4.x, 4); e0 = cpk - t; __builtin_memcpy(&t, &g4.y, 4); e1 = cpk - t; \
+      __builtin_memcpy(&t, &g4.z, 4); e2 = cpk - t; __builtin_memcpy(&t, &g4.w, 4); e3 = cpk - t; } \
+    __builtin_amdgcn_sched_barrier(0); \
+    q0 = __builtin_amdgcn_sdot2(e0, e0, class_off, false); q1 = __builtin_amdgcn_sdot2(e1, e1, class_off, false); \
+    q2 = __builtin_amdgcn_sdot2(e2, e2, class_off, false); q3 = __builtin_amdgcn_sdot2(e3, e3, class_off, false); \
+    __builtin_amdgcn_sched_barrier(0); \
+    q0 = q0 < cap ? q0 : cap; q1 = q1 < cap ? q1 : cap; q2 = q2 < cap ? q2 : cap; q3 = q3 < cap ? q3 : cap; \
+    __builtin_amdgcn_sched_barrier(0); \
+    f0 = *reinterpret_cast<const double*>(t0 + q0); f1 = *reinterpret_cast<const double*>(t0 + q1); \
+    f2 = *reinterpret_cast<const double*>(t0 + q2); f3 = *reinterpret_cast<const double*>(t0 + q3); }
+  double a0, a1, a2, a3, b0, b1, b2, b3;
+  int4 ga = row4[0], gb4 = row4[1];
+  if (skip > 0) ga.x = kGenPad4;
+  if (skip > 1) ga.y = kGenPad4;
+  if (skip > 2) ga.z = kGenPad4;
+  EG_FACTORS(ga, a0, a1, a2, a3)
+  const int pairs = groups >> 1;
+  for (int p = 0; p < pairs; ++p) {          // a holds group 2p
+    ga = row4[2 * p + 2];
+    EG_FACTORS(gb4, b0, b1, b2, b3)
+    __builtin_amdgcn_sched_barrier(0);        // the four table reads stay in flight ahead of the multiply chain
+    s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+    gb4 = row4[2 * p + 3];
+    EG_FACTORS(ga, a0, a1, a2, a3)             // (on the last trip of an even count: a group of padding, never multiplied)
+    __builtin_amdgcn_sched_barrier(0);
+    s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+  }
+  if (groups & 1) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; }
+#undef EG_FACTORS
+  return s;
+}
 // Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
+// kLatency: small-batch kernel (`table` = byte offset of the radius class inside sl.dr16, xy4 = the candidate's packed
+// coordinates); otherwise the throughput kernel (`table` = byte offset of the class inside sm.dr, `cell`).
 template <bool kLatency>
-__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
-                                              double cf, int cell) {
-  const double s = (chunk_product<kLatency>(dr, lane, 0, ngen_s, te, cell, 0) * cf) * size_factor;
+__device__ __forceinline__ double chunk_score(int table, double size_factor, int lane, int ngen_s, int r, double te,
+                                              double cf, int cell, int xy4) {
+  double p;
+  if constexpr (kLatency) p = chunk_product_latency(table, 0, ngen_s, te, xy4);
+  else p = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, 0, ngen_s, te, cell, 0);
+  const double s = (p * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
 // ... continuing the product kept from the last search of the same (year, variant) when there is one
 template <bool kLatency>
-__device__ __forceinline__ double chunk_score(const double* dr, double size_factor, int lane, int ngen_s, int r, double te,
-                                              double cf, int cell, PrefixCache& cache, int key, int stage) {
+__device__ __forceinline__ double chunk_score(int table, double size_factor, int lane, int ngen_s, int r, double te,
+                                              double cf, int cell, int xy4, PrefixCache& cache, int key, int stage) {
   double s = te; int k0 = 0;
   if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
-  s = chunk_product<kLatency>(dr, lane, k0, ngen_s, s, cell, stage);
+  if constexpr (kLatency) s = chunk_product_latency(table, k0, ngen_s, s, xy4);
+  else s = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, k0, ngen_s, s, cell, stage);
   cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
   return r < kCells ? s : 0.0;
@@ -626,7 +670,7 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long th1 = __builtin_readcyclecounter();
 #endif
-    const double s = chunk_score<true>(sm.dr + rc * kD2Stride, size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, cache, (yi << 8) | v, 1);
+    const double s = chunk_score<true>(rc * (kD2Stride * 16), size_factor, lane, ngen_s, r, c.te, c.cf, (int)c.cell, (int)c.pad, cache, (yi << 8) | v, 1);
 #ifdef EG_STAMPS
     const unsigned long long th2 = __builtin_readcyclecounter();
 #endif
@@ -647,7 +691,8 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   const int info = __builtin_amdgcn_readfirstlane(sm.type_info[type]);      // uniform: list address arithmetic on the scalar unit
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
-  const double* dr = sm.dr + rc * kD2Stride;
+  // factor table of the radius class: byte offset inside sl.dr16 (small-batch kernel) / inside the LDS block (sm.dr)
+  const int table = kHelpers > 0 ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
@@ -669,7 +714,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
 #endif
-    const double s0 = chunk_score<true>(dr, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell, cache0, (yi << 8) | v, 0);
+    const double s0 = chunk_score<true>(table, size_factor, lane, ngen_s, lane, c.te, c.cf, (int)c.cell, (int)c.pad, cache0, (yi << 8) | v, 0);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
@@ -705,7 +750,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     const int r = chunk * kWave + lane;
     const double base = (c.te * c.cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
     if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
-    const double te_cur = c.te, cf_cur = c.cf, m03_cur = c.m03; const int cell_cur = (int)c.cell;
+    const double te_cur = c.te, cf_cur = c.cf, m03_cur = c.m03; const int cell_cur = (int)c.cell, xy_cur = (int)c.pad;
     if (chunk + 1 < kChunks) c = list[r + kWave];
 #ifdef EG_STAMPS
     if (stamps) stamps[8] += 1;
@@ -714,7 +759,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     // the single-wave kernel keeps the products of chunks 0 and 1, the episode wave of the helper kernel that of chunk 0
     // (the kept products are used by the small-batch kernel only: in the throughput kernel the extra live registers cost
     //  more than the shorter loops give back)
-    const double s = chunk_score<(kHelpers > 0)>(dr, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur);
+    const double s = chunk_score<(kHelpers > 0)>(table, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur, xy_cur);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
@@ -928,7 +973,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // (the helper also brings the 8 KB factor table into LDS: it has nothing else to do until the first search, and the
     //  barrier of that search orders its LDS writes before anybody's reads)
-    if (wave > 0) { load_factor_table(T, lane); helper_loop(T, lane, wave); return; }
+    if (wave > 0) { load_latency_tables(T, lane); helper_loop(T, lane, wave); return; }
     __builtin_amdgcn_s_setprio(3);      // the episode wave is the critical path: it wins issue arbitration over helper waves
     // LDS arrives with whatever the previous workgroup on this CU left in it: a stale word that happens to equal a
     // sequence number would read as "result ready".  The flags start at 0 (sequence numbers start at 1); the helper
@@ -1165,6 +1210,17 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
+        if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
+          // The helper may still be evaluating its chunk of the search that just ended (its result is only waited for
+          // when it can matter), and it reads the list up to the padding behind the last generator: the new entry must
+          // not appear under it.  By now it has almost always finished.
+          while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[0]) != (int)search_seq) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+          if (lane == 0) {
+            const int gi = cell / kGrid;
+            sl.gpk[ep.ngen - 1] = (4 * gi) | ((4 * (cell - gi * kGrid)) << 16);
+          }
+        }
         EG_TE(12);
       } else if (action < kFirstOther) {
         EG_MARKG(20);

@@ -282,3 +282,45 @@ def test_rollout_ignores_what_is_left_in_lds(engine, world):
     big = engine.rollout_batch(pol, 97531, 4096)     # the one-wave kernel on the same episodes
     for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_draws"):
         assert getattr(big, name)[:n].tobytes() == getattr(clean, name).tobytes(), name
+
+
+def test_both_kernels_agree_on_random_policies(world):
+    """A short version of scripts/soak.py inside the suite: random policies (perturbed tables, stall counters, best lists,
+    20 % replays) through both kernels, identical bytes demanded.  Seed 1 is the stream on which a list-append race of
+    the small-batch kernel (the helper wave still reading the generator list when the next generator was appended)
+    first showed, in its fourth policy."""
+    engines = {}
+    for mode in ("0", "all"):
+        os.environ["EIRGRID_HELPER_WAVES"] = mode
+        try:
+            engines[mode] = Engine(world, device=0)
+        finally:
+            del os.environ["EIRGRID_HELPER_WAVES"]
+    rng = np.random.default_rng(1)
+    try:
+        for trial in range(8):
+            pol = ActionWeights()
+            run = [rng.integers(0, 61, int(rng.choice([0, 0, 1, 2, 5, 9]))).tolist() for _ in range(26)]
+            dfl = [(3 * rng.choice([8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14], int(rng.choice([0, 1, 2, 3])))).tolist() for _ in range(26)]
+            nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
+            pol.apply_episode([float(rng.choice([-5e4, 3e5])), 0.7, float(rng.choice([4e10, 9e11])), 1.0], nr,
+                              np.array([a for l in run for a in l], np.uint8), nd, np.array([a for l in dfl for a in l], np.uint8))
+            w, dw, cw = pol.tables()
+            pol.set_tables(np.clip(w * 10 ** rng.uniform(-1.5, 1.0, w.shape), 1e-4, 0.999),
+                           np.clip(dw * 10 ** rng.uniform(-1.5, 1.0, dw.shape), 1e-4, 0.999), cw * rng.uniform(0.2, 3.0, cw.shape))
+            pol.set("iterations_without_improvement", int(rng.choice([0, 50, 150, 480, 520, 1400, 4000])))
+            pol.set("learning_rate", float(rng.uniform(0.05, 0.5))); pol.set("exploration_rate", float(rng.uniform(0.0, 0.9)))
+            if trial % 3 == 2:
+                pol.set("has_count_weights", 0)
+            n = 1536; seed = int(rng.integers(1, 2**40)); first = int(rng.integers(0, 2**20))
+            mask = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+            a = engines["0"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+            b = engines["all"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+            for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
+                assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (trial, name)
+            for e in range(n):
+                g = int(a.n_gens[e])
+                assert a.gen_cell[e, :g].tobytes() == b.gen_cell[e, :g].tobytes(), (trial, e)
+    finally:
+        for eng in engines.values():
+            eng.close()
