@@ -548,20 +548,20 @@ struct YearTerms { double2 g_cc; double g_m03, g_t12, o_v, o_c; int g_t; };
 struct YearSums { double gcost, optot, offs, ocost, co2, tg, ig, sg; int opcnt; };
 
 __device__ __forceinline__ void year_gather_gens(const DevTables& T, int lane, int yi, int base, int ngen_s, YearTerms& t) {
-  const double* ccy = T.cc() + (size_t)yi * kTypes * kYears * kMults * 2;
+  const double* ccy = T.cc() + (unsigned)yi * kTypes * kYears * kMults * 2;
   const int g = base + lane;
   const bool valid = g < ngen_s;
   const int gc = valid ? sm.gcell[g] : 0, bm = valid ? sm.gbm[g] : 0;
   const int cell = gc & 0xFFF, b = bm & 31, m = bm >> 5;
   t.g_t = gc >> 12;
-  t.g_cc = *reinterpret_cast<const double2*>(ccy + ((size_t)(t.g_t * kYears + b) * kMults + m) * 2);
-  t.g_m03 = T.m03()[cell]; t.g_t12 = T.t12()[(size_t)yi * kTypes + t.g_t];
+  t.g_cc = *reinterpret_cast<const double2*>(ccy + ((unsigned)(t.g_t * kYears + b) * kMults + m) * 2);
+  t.g_m03 = T.m03()[cell]; t.g_t12 = T.t12()[(unsigned)yi * kTypes + t.g_t];
 }
 __device__ __forceinline__ void year_gather_offsets(const DevTables& T, int lane, int yi, int base, int noff_s, YearTerms& t) {
   const int k = base + lane;
   const int p = k < noff_s ? sm.opack[k] : 0;
   const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
-  t.o_v = T.offv()[((size_t)yi * kOffsetTypes + ot) * kYears + b]; t.o_c = T.offc()[((size_t)yi * kOffsetTypes + ot) * kMults + m];
+  t.o_v = T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + b]; t.o_c = T.offc()[((unsigned)yi * kOffsetTypes + ot) * kMults + m];
 }
 // the first 64 entries of each list are requested here; year_fold gathers the rest (rare) itself
 __device__ __forceinline__ YearTerms year_gather(const DevTables& T, int lane, int yi, int ngen_s, int noff_s) {
@@ -1178,9 +1178,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         const int t = action / 3, m = action - 3 * t;
         ep.bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ep.ngen) * 16ull;
         // terms that depend only on (year, type, multiplier) are requested before the search and land while it runs
-        const double2 ccv = *reinterpret_cast<const double2*>(T.cc() + ((((size_t)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
-        const double cc_prev = yi > 0 ? T.cc()[((((size_t)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
-        const double t12v = T.t12()[(size_t)yi * kTypes + t];
+        const double2 ccv = *reinterpret_cast<const double2*>(T.cc() + ((((unsigned)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
+        const double cc_prev = yi > 0 ? T.cc()[((((unsigned)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
+        const double t12v = T.t12()[(unsigned)yi * kTypes + t];
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
@@ -1230,9 +1230,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
         wave_sync();
         ep.noff += 1;
-        a.offs += T.offv()[((size_t)yi * kOffsetTypes + ot) * kYears + yi];
-        a.ocost += T.offc()[((size_t)yi * kOffsetTypes + ot) * kMults + m];
-        if (yi > 0) a.ocost_prev += T.offc()[((size_t)(yi - 1) * kOffsetTypes + ot) * kMults + m];
+        a.offs += T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + yi];
+        a.ocost += T.offc()[((unsigned)yi * kOffsetTypes + ot) * kMults + m];
+        if (yi > 0) a.ocost_prev += T.offc()[((unsigned)(yi - 1) * kOffsetTypes + ot) * kMults + m];
         EG_TE(13);
       }
       // 57..59 carry an empty generator id (core.rs:117-119): the lookup fails, nothing changes.  60: DoNothing.
