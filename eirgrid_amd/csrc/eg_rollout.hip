@@ -1479,8 +1479,16 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   __shared__ uint32_t s_key[8];
   __shared__ DevState st;
   __shared__ int s_winner, s_improved, s_randomized_main, s_owned;
+  __shared__ __align__(16) uint8_t s_best[snap::kBestCap]; __shared__ __align__(16) uint8_t s_bestd[snap::kBestCap];      // the best lists as they were before this update
+  __shared__ int s_off[2][Y + 1];
+  __shared__ double s_ln_boost;
+  __shared__ rm::DeficitContrast s_dc;
   __shared__ int s_prefix[2][Y + 1];
   const int tid = threadIdx.x;
+#ifdef EG_STAMPS
+  __shared__ unsigned long long dbg_t[16];      // diagnostic: phase boundaries (100 MHz counter), see scripts/apply_phases.py
+  if (tid == 0) dbg_t[0] = wall_clock64();
+#endif
   double* pol = reinterpret_cast<double*>(snap_base + snap::pol);
   int32_t* best_off = reinterpret_cast<int32_t*>(snap_base + snap::best_off);
   int32_t* bestd_off = reinterpret_cast<int32_t*>(snap_base + snap::bestd_off);
@@ -1496,6 +1504,21 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     for (int r = 0; r < n_cands; ++r) v += reinterpret_cast<const long long*>(packets + (size_t)r * EG_PACKET_BYTES)[i];
     return v;
   };
+  // Everything the contrast steps read is requested now and lands while the serial pieces run: the old best lists go to
+  // LDS (the steps walk them per table entry), each thread's table entries and statistics into its registers.
+  constexpr int kPen = 8, kMild = 8 + Y * NA, kDcnt = 8 + 2 * Y * NA;
+  {
+    const uint32_t* b4 = reinterpret_cast<const uint32_t*>(best_actions); const uint32_t* d4 = reinterpret_cast<const uint32_t*>(bestd_actions);
+    reinterpret_cast<uint32_t*>(s_best)[tid] = b4[tid]; reinterpret_cast<uint32_t*>(s_bestd)[tid] = d4[tid];      // kBestCap = 4 x 1024 bytes
+    if (tid <= Y) { s_off[0][tid] = best_off[tid]; s_off[1][tid] = bestd_off[tid]; }
+  }
+  double w_in[2] = {0.0, 0.0}, pen_in[2] = {0.0, 0.0}, dw_in = 0.0; long long dcnt_in = 0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + 1024 * k;
+    if (i < Y * NA) { const int y = i / NA, a = i - y * NA; w_in[k] = pol[y * snap::kPolRow + a]; pen_in[k] = (double)stat(kPen + i) + (double)stat(kMild + i); }
+  }
+  if (tid < Y * ND) { const int y = tid / ND, sl = tid - y * ND; dw_in = pol[y * snap::kPolRow + snap::kPolDw + sl]; dcnt_in = stat(kDcnt + tid); }
   if (tid == 64) {
     st = *gstate;
     // the batch's candidate: highest score, ties to the lowest global index (eg_policy_apply_packet)
@@ -1513,6 +1536,10 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     }
     s_improved = improved ? 1 : 0;
   }
+  // the two transcendental-heavy scalars of the contrast steps depend on the old state and the episode count only: each is
+  // evaluated once, on a wave of its own, beside the pieces above (every thread used to evaluate them for itself)
+  if (tid == 128) s_ln_boost = rm::contrast_ln_boost(gstate->learning_rate, gstate->stall);
+  if (tid == 192) s_dc = rm::deficit_contrast(gstate->learning_rate, gstate->stall + (uint32_t)stat(0));   // the stall counter after a batch without improvement
   if (tid == 0) {
     unsigned long long state = noise_seed;      // rand_core seed_from_u64 (HostRng)
     for (int i = 0; i < 8; ++i) {
@@ -1522,8 +1549,10 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     }
   }
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[1] = wall_clock64();
+#endif
   const long long n_ok = stat(0), n_qual = stat(2);
-  constexpr int kPen = 8, kMild = 8 + Y * NA, kDcnt = 8 + 2 * Y * NA;
   const bool contrast = st.has_best && st.has_lists && n_qual > 0;
   const bool randomize_main = contrast && st.stall > 1200u;
   // the noise stream is only needed beyond 1200 stalled episodes; the deficit table may need it even if the main one
@@ -1531,6 +1560,9 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   const bool maybe_noise = st.stall + (uint32_t)n_ok > 1200u;
   if (maybe_noise && tid < kBlocks) chacha12_block(s_key, (unsigned long long)tid, s_noise + 16 * tid);
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[2] = wall_clock64();
+#endif
   auto draw = [&](int j) {      // j-th gen::<f64>() of the stream
     const unsigned long long v = ((unsigned long long)s_noise[2 * j + 1] << 32) | s_noise[2 * j];
     return (double)(v >> 11) * (1.0 / 9007199254740992.0);
@@ -1538,19 +1570,25 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 
   // ---- apply_contrast_learning over the batch ----
   if (contrast) {
-    const double ln_boost = rm::contrast_ln_boost(st.learning_rate, st.stall);
-    for (int i = tid; i < Y * NA; i += 1024) {
+    const double ln_boost = s_ln_boost;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      const int i = tid + 1024 * k2;
+      if (i >= Y * NA) break;
       const int y = i / NA, a = i - y * NA;
       int occ = 0;
-      for (int k = best_off[y]; k < best_off[y + 1]; ++k) occ += best_actions[k] == a ? 1 : 0;
-      for (int k = bestd_off[y]; k < bestd_off[y + 1]; ++k) occ += bestd_actions[k] == a ? 1 : 0;
-      const double L = (double)n_qual * (double)occ * ln_boost + ((double)stat(kPen + i) + (double)stat(kMild + i)) / 4294967296.0;
-      double w = rm::nudge(pol[y * snap::kPolRow + a], L);
+      for (int k = s_off[0][y]; k < s_off[0][y + 1]; ++k) occ += s_best[k] == a ? 1 : 0;
+      for (int k = s_off[1][y]; k < s_off[1][y + 1]; ++k) occ += s_bestd[k] == a ? 1 : 0;
+      const double L = (double)n_qual * (double)occ * ln_boost + pen_in[k2] / 4294967296.0;
+      double w = rm::nudge(w_in[k2], L);
       if (randomize_main) w = rm::noise(w, draw(i));
       pol[y * snap::kPolRow + a] = w;
     }
   }
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[3] = wall_clock64();
+#endif
 
   // ---- update_best_strategy with the batch's candidate ----
   if (tid == 0) {
@@ -1574,6 +1612,9 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     st.improved_last = improved ? 1 : 0;
   }
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[4] = wall_clock64();
+#endif
   const bool improved = s_improved != 0;
   if (improved) {      // the candidate's lists become the best lists; the main weights of this moment are kept beside them
     const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_PACKET_BYTES);
@@ -1601,26 +1642,29 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 
   // ---- apply_deficit_contrast_learning: the same factor for every episode (it depends on the stall counter only) ----
   if (!improved && st.has_best && st.has_lists) {
-    const rm::DeficitContrast dc = rm::deficit_contrast(st.learning_rate, st.stall);
+    const rm::DeficitContrast dc = s_dc;      // st.stall is the old counter + n_ok here (no improvement)
     if (dc.active) {
       const bool randomize = st.stall > 1200u;
       const int first_draw = s_randomized_main ? kMainDraws : 0;
-      for (int i = tid; i < Y * ND; i += 1024) {
+      for (int i = tid; i < Y * ND; i += 1024) {      // (Y * ND < 1024: one entry per thread, the one requested at the start)
         const int y = i / ND, sl = i - y * ND;
         int occ = 0;
-        for (int k = bestd_off[y]; k < bestd_off[y + 1]; ++k) {
-          const int a = bestd_actions[k];
+        for (int k = s_off[1][y]; k < s_off[1][y + 1]; ++k) {
+          const int a = s_bestd[k];
           const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
           occ += slot == sl ? 1 : 0;
         }
-        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)stat(kDcnt + i) * dc.ln_pen;
-        double w = rm::nudge(pol[y * snap::kPolRow + snap::kPolDw + sl], L);
+        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)dcnt_in * dc.ln_pen;
+        double w = rm::nudge(dw_in, L);
         if (randomize) w = rm::noise(w, draw(first_draw + i));
         pol[y * snap::kPolRow + snap::kPolDw + sl] = w;
       }
     }
   }
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[5] = wall_clock64();
+#endif
 
   // ---- what eg_upload_snapshot derives: row sums in table order, scalars ----
   if (tid < Y) {
@@ -1634,7 +1678,21 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   // this rank's statistics buffer is ready for the next batch's epilogue (when it is also `packets`, every read of it
   // happened before the barriers above)
   __syncthreads();
+#ifdef EG_STAMPS
+  if (tid == 0) dbg_t[6] = wall_clock64();
+#endif
   for (int i = tid; i < EG_STATS_LEN; i += 1024) zero_stats[i] = 0;
+#ifdef EG_STAMPS
+  __syncthreads();      // the unused statistics slots 3..7 carry the phase durations out (after the zeroing above)
+  if (tid == 0) {
+    const unsigned long long t_end = wall_clock64();
+    zero_stats[3] = (long long)(dbg_t[2] - dbg_t[0]);      // state, winner, noise key, noise blocks
+    zero_stats[4] = (long long)(dbg_t[3] - dbg_t[2]);      // contrast step on the main table
+    zero_stats[5] = (long long)(dbg_t[4] - dbg_t[3]);      // best-strategy bookkeeping (one thread)
+    zero_stats[6] = (long long)(dbg_t[5] - dbg_t[4]);      // list copies / deficit contrast
+    zero_stats[7] = (long long)(t_end - dbg_t[5]);         // row sums, derive_state, zeroing
+  }
+#endif
 }
 
 }  // namespace
