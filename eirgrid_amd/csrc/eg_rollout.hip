@@ -684,9 +684,11 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
   }
 }
 
-template <int kHelpers>
+// `between` is called once the candidate records are requested (and, in the small-batch kernel, the helper has its
+// command): whatever the caller has to do before it needs the result goes there and runs under the records' latency.
+template <int kHelpers, class Between>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
-                                            double* best_m03, PrefixCache& cache0, uint32_t* seq = nullptr,
+                                            double* best_m03, PrefixCache& cache0, Between&& between, uint32_t* seq = nullptr,
                                             unsigned long long* stamps = nullptr) {
   const int info = __builtin_amdgcn_readfirstlane(sm.type_info[type]);      // uniform: list address arithmetic on the scalar unit
   const int v = info & 15, rc = (info >> 4) & 15;
@@ -710,6 +712,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     const uint32_t sq = *seq;
     if (lane == 0) { sm.cmd[sq & 1][0] = yi | (v << 8) | (rc << 12); sm.cmd[sq & 1][1] = ngen_s; }
     wg_barrier_lds();
+    between();
 #ifdef EG_STAMPS
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
@@ -746,6 +749,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     if (stamps) stamps[10] += __builtin_readcyclecounter() - tg1;
 #endif
   }
+  if constexpr (kHelpers == 0) between();
   for (int chunk = first; more && chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
     const double base = (c.te * c.cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
@@ -1176,19 +1180,23 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       action = __builtin_amdgcn_readfirstlane(action);
       if (action < kFirstOffset) {
         const int t = action / 3, m = action - 3 * t;
-        ep.bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ep.ngen) * 16ull;
-        // terms that depend only on (year, type, multiplier) are requested before the search and land while it runs
-        const double2 ccv = *reinterpret_cast<const double2*>(T.cc() + ((((unsigned)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
-        const double cc_prev = yi > 0 ? T.cc()[((((unsigned)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2] : 0.0;
-        const double t12v = T.t12()[(unsigned)yi * kTypes + t];
+        // terms that depend only on (year, type, multiplier) are requested inside the search, right behind its own
+        // loads, and land while it runs
+        double2 ccv; double cc_prev = 0.0, t12v;
+        auto between = [&]() {
+          ep.bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ep.ngen) * 16ull;
+          ccv = *reinterpret_cast<const double2*>(T.cc() + ((((unsigned)yi * kTypes + t) * kYears + yi) * kMults + m) * 2);
+          if (yi > 0) cc_prev = T.cc()[((((unsigned)(yi - 1) * kTypes + t) * kYears + yi) * kMults + m) * 2];
+          t12v = T.t12()[(unsigned)yi * kTypes + t];
+        };
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq, stamps));
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, &search_seq, stamps));
         stamps[11] += 1;
 #else
         double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, &search_seq));
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, &search_seq));
 #endif
         EG_T1(1);
         if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
@@ -1373,7 +1381,7 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   __syncthreads();
   double score = 0.0;
   PrefixCache pc0 = {0.0, -1, 0};
-  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr, pc0);
+  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr, pc0, []() {});
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
