@@ -53,6 +53,13 @@ def test_config2_1024_episodes_vs_tabled_oracle(engine, world):
     for e in range(1024):
         st, ref = O.run_episode_tabled(tb, O.OracleWeights(), 12345 + e)
         assert_episode_equal(res, e, ref, "config2")
+    # eg_fetch_record: one episode's record on its own
+    one = engine.fetch_record(777)
+    for name in ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "run_log", "def_log", "n_gens", "gen_cell", "gen_pack",
+                 "n_offsets", "off_pack", "n_draws", "bytes_moved"):
+        assert getattr(one, name)[0].tobytes() == getattr(res, name)[777].tobytes(), name
+    with pytest.raises(Exception):
+        engine.fetch_record(1024)
 
 
 def test_replay_mask_and_best_lists(engine, world):
@@ -321,6 +328,39 @@ def test_both_kernels_agree_on_random_policies(world):
             for e in range(n):
                 g = int(a.n_gens[e])
                 assert a.gen_cell[e, :g].tobytes() == b.gen_cell[e, :g].tobytes(), (trial, e)
+    finally:
+        for eng in engines.values():
+            eng.close()
+
+
+def test_capacity_overflow_is_reported_not_hidden(world):
+    """Maximum sizes: a best strategy with 30 generator additions in every year, replayed (and double-recorded, SURVEY
+    Q15), runs past EG_MAX_GENS / EG_RUN_CAP.  Such an episode must end with EG_EP_OVERFLOW in both kernels, with
+    identical bytes, never with a silently truncated result; seeded episodes of the same batch are untouched."""
+    engines = {}
+    for mode in ("0", "all"):
+        os.environ["EIRGRID_HELPER_WAVES"] = mode
+        try:
+            engines[mode] = Engine(world, device=0)
+        finally:
+            del os.environ["EIRGRID_HELPER_WAVES"]
+    try:
+        pol = ActionWeights()
+        nr = np.full(26, 30, np.int32); nd = np.zeros(26, np.int32)
+        pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.full(26 * 30, 36, np.uint8), nd, np.zeros(0, np.uint8))   # 36 = BatteryStorage 100 %
+        n = 64
+        mask = (np.arange(n) % 2 == 0).astype(np.uint8)
+        a = engines["0"].rollout_batch(pol, 5, n, replay_mask=mask)
+        b = engines["all"].rollout_batch(pol, 5, n, replay_mask=mask)
+        assert (a.status[mask == 1] == -1).all(), "EG_EP_OVERFLOW expected for every replay episode"     # include/eirgrid_hip.h
+        assert (a.status[mask == 0] == 0).all()
+        for name in ("status", "metrics", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws"):
+            assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
+        assert (a.n_gens <= 512).all() and (a.n_run.sum(axis=1) <= 2048).all()
+        tb = _tabled(world)
+        for e in (1, 33, 63):      # the seeded episodes of the batch against the oracle
+            st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 5 + e, replay=False)
+            assert_episode_equal(a, e, ref, "beside overflowing episodes")
     finally:
         for eng in engines.values():
             eng.close()
