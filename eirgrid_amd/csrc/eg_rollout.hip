@@ -10,6 +10,10 @@
 // sum-and-walk) are replaced by a parallel form where that provably gives the same decision (weighted_pick).
 // Build: -ffp-contract=off (no FMA).  Further kernels: k_apply_update (the batch update, on the device),
 // k_stalled_tables, k_pick_best, k_update_stats, k_place.
+// Two measured facts shape the code: (1) in the small-batch kernel a lone wave issues one instruction per turn of its
+// SIMD, whatever the instruction — the hot loops are written for instruction count, scalar and wait instructions
+// included (chunk_product_latency); (2) gfx950 allocates LDS in 1280-byte granules — the throughput kernel's Smem is
+// held at ten of them (twelve episodes per CU), the small-batch kernel spends LDS freely (SmemLatency).
 //
 // Reference (paths relative to /root/reference/aiSimulator/src/):
 //   episode        core/simulation.rs:22-317, core/iteration.rs:57-74
