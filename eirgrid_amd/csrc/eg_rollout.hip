@@ -441,6 +441,9 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
 //    subtract, the accumulator move, the dot product, the cap, the table read and the multiply;
 //  * one straight-line loop body of two groups, so the wait counts stay exact; padding multiplies by 1.0.
 // k0: generators [0, k0) are already in s_init (kept product); the first group is masked accordingly.
+// kMaskTail (helper wave): entries behind the list are not trusted to be padding — the episode wave may append the next
+// generator while this chunk is still being evaluated — so the last group is taken out of the pipeline and masked.
+template <bool kMaskTail>
 __device__ __forceinline__ double chunk_product_latency(int class_off, int k0, int ngen_s, double s_init, int xy4) {
   short2v cpk; __builtin_memcpy(&cpk, &xy4, 4);
   double s = s_init;
@@ -464,6 +467,34 @@ __device__ __forceinline__ double chunk_product_latency(int class_off, int k0, i
     f0 = *reinterpret_cast<const double*>(t0 + q0); f1 = *reinterpret_cast<const double*>(t0 + q1); \
     f2 = *reinterpret_cast<const double*>(t0 + q2); f3 = *reinterpret_cast<const double*>(t0 + q3); }
   double a0, a1, a2, a3, b0, b1, b2, b3;
+  if constexpr (kMaskTail) {
+    const int last = groups - 1, tail = ngen_s & 3;
+    if (last > 0) {      // groups [0, last) through the pipeline (its look-ahead reads are never multiplied)
+      int4 ga = row4[0], gb4 = row4[1];
+      if (skip > 0) ga.x = kGenPad4;
+      if (skip > 1) ga.y = kGenPad4;
+      if (skip > 2) ga.z = kGenPad4;
+      EG_FACTORS(ga, a0, a1, a2, a3)
+      const int pairs = last >> 1;
+      for (int p = 0; p < pairs; ++p) {
+        ga = row4[2 * p + 2];
+        EG_FACTORS(gb4, b0, b1, b2, b3)
+        __builtin_amdgcn_sched_barrier(0);
+        s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+        gb4 = row4[2 * p + 3];
+        EG_FACTORS(ga, a0, a1, a2, a3)
+        __builtin_amdgcn_sched_barrier(0);
+        s = s * b0; s = s * b1; s = s * b2; s = s * b3;
+      }
+      if (last & 1) { s = s * a0; s = s * a1; s = s * a2; s = s * a3; }
+    }
+    int4 gl = row4[last];
+    if (last == 0) { if (skip > 0) gl.x = kGenPad4; if (skip > 1) gl.y = kGenPad4; if (skip > 2) gl.z = kGenPad4; }
+    if (tail != 0) { if (tail < 2) gl.y = kGenPad4; if (tail < 3) gl.z = kGenPad4; gl.w = kGenPad4; }
+    EG_FACTORS(gl, a0, a1, a2, a3)
+    s = s * a0; s = s * a1; s = s * a2; s = s * a3;
+    return s;
+  }
   int4 ga = row4[0], gb4 = row4[1];
   if (skip > 0) ga.x = kGenPad4;
   if (skip > 1) ga.y = kGenPad4;
@@ -491,7 +522,7 @@ template <bool kLatency>
 __device__ __forceinline__ double chunk_score(int table, double size_factor, int lane, int ngen_s, int r, double te,
                                               double cf, int cell, int xy4) {
   double p;
-  if constexpr (kLatency) p = chunk_product_latency(table, 0, ngen_s, te, xy4);
+  if constexpr (kLatency) p = chunk_product_latency<false>(table, 0, ngen_s, te, xy4);
   else p = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, 0, ngen_s, te, cell, 0);
   const double s = (p * cf) * size_factor;
   return r < kCells ? s : 0.0;
@@ -502,7 +533,7 @@ __device__ __forceinline__ double chunk_score(int table, double size_factor, int
                                               double cf, int cell, int xy4, PrefixCache& cache, int key, int stage) {
   double s = te; int k0 = 0;
   if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
-  if constexpr (kLatency) s = chunk_product_latency(table, k0, ngen_s, s, xy4);
+  if constexpr (kLatency) s = stage ? chunk_product_latency<true>(table, k0, ngen_s, s, xy4) : chunk_product_latency<false>(table, k0, ngen_s, s, xy4);
   else s = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, k0, ngen_s, s, cell, stage);
   cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
@@ -1223,11 +1254,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
-          // The helper may still be evaluating its chunk of the search that just ended (its result is only waited for
-          // when it can matter), and it reads the list up to the padding behind the last generator: the new entry must
-          // not appear under it.  By now it has almost always finished.
-          while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[0]) != (int)search_seq) __builtin_amdgcn_s_sleep(1);
-          asm volatile("" ::: "memory");
+          // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
+          //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
           if (lane == 0) {
             const int gi = cell / kGrid;
             sl.gpk[ep.ngen - 1] = (4 * gi) | ((4 * (cell - gi * kGrid)) << 16);
