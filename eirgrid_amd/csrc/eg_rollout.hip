@@ -643,6 +643,41 @@ __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, 
     for (int j = 0; j < cnt; ++j) { s.offs += readlane_f64(ov, j); s.ocost += readlane_f64(oc, j); }
   }
 }
+// The same fold over generators [g_from, g_to) and offsets [o_from, o_to) only (every block gathered here): a year's sums
+// can be started before the year's lists are final — they only grow at their ends — and finished afterwards, with the
+// additions in the same order (helper wave, small-batch kernel).
+__device__ __forceinline__ void year_fold_range(const DevTables& T, int lane, int yi, int g_from, int g_to, int o_from, int o_to,
+                                                bool carry, YearSums& s) {
+  YearTerms t; t.g_cc.x = 0.0; t.g_cc.y = 0.0; t.g_m03 = 0.0; t.g_t12 = 0.0; t.o_v = 0.0; t.o_c = 0.0; t.g_t = 0;
+  if (g_from < g_to) year_gather_gens(T, lane, yi, g_from, g_to, t);      // both requests first, one latency
+  if (o_from < o_to) year_gather_offsets(T, lane, yi, o_from, o_to, t);
+  for (int base = g_from; base < g_to; base += kWave) {
+    if (base > g_from) year_gather_gens(T, lane, yi, base, g_to, t);
+    const double2 cc = t.g_cc;
+    const int ty = t.g_t;
+    const double op = (t.g_m03 + t.g_t12) + cc.y;
+    double out = 0.0, co2 = 0.0; int cls = 0;
+    if (!carry) { out = sm.type_out[ty]; co2 = sm.type_co2[ty]; cls = (sm.type_info[ty] >> 12) & 3; }
+    const int cnt = g_to - base < kWave ? g_to - base : kWave;
+    for (int j = 0; j < cnt; ++j) {
+      s.gcost += readlane_f64(cc.x, j);
+      s.optot += readlane_f64(op, j);
+      if (!carry) {
+        const double oj = readlane_f64(out, j);
+        const int cj = __builtin_amdgcn_readlane(cls, j);
+        s.co2 += readlane_f64(co2, j);
+        if (cj == 1) s.ig += oj; else if (cj == 2) s.sg += oj; else s.tg += oj;
+      }
+    }
+    s.opcnt += cnt;
+  }
+  for (int base = o_from; base < o_to; base += kWave) {
+    if (base > o_from) year_gather_offsets(T, lane, yi, base, o_to, t);
+    const double ov = t.o_v, oc = t.o_c;
+    const int cnt = o_to - base < kWave ? o_to - base : kWave;
+    for (int j = 0; j < cnt; ++j) { s.offs += readlane_f64(ov, j); s.ocost += readlane_f64(oc, j); }
+  }
+}
 // starting values of the sums for year yi: zero, or the existing-plant prefix of that year (class sums only when they
 // do not carry over)
 // The helper wave asks for NEXT year's values, which are not in LDS yet: it reads the tables; the episode wave reads the
@@ -677,6 +712,8 @@ __device__ __forceinline__ YearSums year_sums_init_current() {
 __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h) {
   const double size_factor = T.size_factor;
   PrefixCache cache = {0.0, -1, 0};
+  YearSums pre; int pre_year = -1, pre_g = 0, pre_o = 0;      // sums of year pre_year over generators [0, pre_g) / offsets [0, pre_o)
+  pre.gcost = pre.optot = pre.offs = pre.ocost = pre.co2 = pre.tg = pre.ig = pre.sg = 0.0; pre.opcnt = 0;
   for (uint32_t sq = 1;; ++sq) {
     wg_barrier_lds();
     const int c0 = __builtin_amdgcn_readfirstlane(sm.cmd[sq & 1][0]);
@@ -685,14 +722,24 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
     if (c0 & kCmdYear) {      // next year's starting sums (year_fold), while the episode wave closes the current year
       const int yi = c0 & 31, ngen = ngen_s & 0xFFFF, noff = (ngen_s >> 16) & 0xFFFF;
       const bool carry = ((c0 >> 8) & 1) != 0;
-      YearSums ys = year_sums_init(T, yi);
-      year_fold(T, lane, yi, ngen, noff, carry, year_gather(T, lane, yi, ngen, noff), ys);
+      // The sums of this year were started a year ago over the lists as they were then (see below): only what has been
+      // added since is folded now, so the episode wave finds them ready.
+      YearSums ys; int g_from = 0, o_from = 0;
+      if (pre_year == yi) { ys = pre; g_from = pre_g; o_from = pre_o; }
+      else ys = year_sums_init(T, yi);
+      year_fold_range(T, lane, yi, g_from, ngen, o_from, noff, carry, ys);
       if (lane == 0) {
         sm.ysum[0] = ys.gcost; sm.ysum[1] = ys.optot; sm.ysum[2] = ys.offs; sm.ysum[3] = ys.ocost;
         sm.ysum[4] = ys.co2; sm.ysum[5] = ys.tg; sm.ysum[6] = ys.ig; sm.ysum[7] = ys.sg; sm.ysum_opcnt = ys.opcnt;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) *(volatile uint32_t*)&sm.yflag = sq;
+      // ... and the year after that is started over the lists as they are now (they only grow at their ends)
+      if (yi + 1 < kYears) {
+        pre = year_sums_init(T, yi + 1);
+        year_fold_range(T, lane, yi + 1, 0, ngen, 0, noff, ((c0 >> 9) & 1) != 0, pre);
+        pre_year = yi + 1; pre_g = ngen; pre_o = noff;
+      }
       continue;
     }
     const int yi = c0 & 31, v = (c0 >> 8) & 15, rc = (c0 >> 12) & 15;
@@ -1318,7 +1365,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       if (yi + 1 < kYears) {
         search_seq += 1; year_seq = search_seq;
         if (lane == 0) {
-          sm.cmd[search_seq & 1][0] = kCmdYear | (yi + 1) | ((int)((carry_mask >> (yi + 1)) & 1u) << 8);
+          sm.cmd[search_seq & 1][0] = kCmdYear | (yi + 1) | ((int)((carry_mask >> (yi + 1)) & 1u) << 8) | ((int)((carry_mask >> (yi + 2)) & 1u) << 9);
           sm.cmd[search_seq & 1][1] = ep.ngen | (ep.noff << 16);
         }
         wg_barrier_lds();
