@@ -94,6 +94,19 @@ def cpu_baseline(world, seconds_budget: float = 20.0):
             "note": "C restatement of the reference algorithm (oracle/eg_oracle.c), not the Rust/rayon binary"}
 
 
+def measured_peak():
+    """Triad bandwidth measured on an MI355X of this pool (scripts/hbm_probe.py -> profiles/*hbm_probe.json), reported beside
+    the datasheet peak that `frac` is priced against; None when no probe result is committed."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_probe.json"))):
+        try:
+            best = float(json.load(open(path))["triad_GBps"])
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +206,7 @@ def main():
                        "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one 32 KB all-gather per update "
                                       "(integer statistics summed in the update kernel)",
                        "episodes_ok_last_batch": ok, "strategy_improvements": trainer.improvements},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "peak_measured": measured_peak(), "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.episodes), "kernel": "k_rollout",
                          "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_episode": bytes_per_launch / max(args.episodes, 1),
