@@ -133,6 +133,9 @@ struct Agg {   // aggregates of the map at the current point of the year (map_ha
 };
 struct State { double net, opinion, balance, cost; };   // ActionResult, simulation_metrics.rs:13-18
 
+// A condition that is the same in every lane, made known to the compiler as such (a scalar branch instead of an
+// exec-masked region with its save / restore instructions).
+#define EG_UNI(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dabs(double a) { return a < 0.0 ? -a : a; }
@@ -835,7 +838,9 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   for (int chunk = first; more && chunk < kChunks; ++chunk) {
     const int r = chunk * kWave + lane;
     const double base = (c.te * c.cf) * size_factor;      // padded with te = 0 beyond the 2601 candidates
-    if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
+    // (throughput kernel: said to be uniform, this is a scalar branch; measured +4.5 % there, -2 % in the small-batch kernel)
+    const bool below = !(readlane_f64(base, 0) >= best);
+    if (chunk > 0 && (kHelpers > 0 ? below : EG_UNI(below))) break;      // sorted descending: lane 0 holds the chunk's bound
     const double te_cur = c.te, cf_cur = c.cf, m03_cur = c.m03; const int cell_cur = (int)c.cell, xy_cur = (int)c.pad;
     if (chunk + 1 < kChunks) c = list[r + kWave];
 #ifdef EG_STAMPS
