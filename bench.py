@@ -152,6 +152,7 @@ def main():
         os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")      # only matters for --force-collectives outside torchrun
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
         else:

@@ -467,7 +467,31 @@ int32_t eg_policy_push(eg_ctx* c, const eg_policy* p, const eg_opts* o) {
   return EG_OK;
 }
 
+namespace {
+int device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, void* d_packet, bool pick);
+int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed, bool local_pick);
+}  // namespace
+
 int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, void* d_packet) {
+  return device_rollout(c, seed, first_index, n, replay_period, d_packet, true);
+}
+int32_t eg_device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed) {
+  return device_apply(c, d_packets, n_packets, d_own_packet, noise_seed, false);
+}
+// One GPU: the best episode is found inside k_apply_update (from the best-score key the rollout epilogue leaves in the
+// statistics), so a step is three launches: k_rollout, k_apply_update, k_stalled_tables.
+int32_t eg_device_step(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, uint64_t noise_seed) {
+  if (!c) return EG_ERR_BAD_ARG;
+  if (n == 0) return EG_OK;
+  int rc = ensure_packet(c);
+  if (rc != EG_OK) return rc;
+  rc = device_rollout(c, seed, first_index, n, replay_period, c->d_packet, false);
+  if (rc != EG_OK) return rc;
+  return device_apply(c, c->d_packet, 1, c->d_packet, noise_seed, true);
+}
+
+namespace {
+int device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, void* d_packet, bool pick) {
   if (!c || !c->snap_valid || !d_packet) { set_error("eg_device_rollout: push a policy first"); return EG_ERR_BAD_ARG; }
   if (n == 0) { c->last_n = 0; return EG_OK; }
   EG_HIP(hipSetDevice(c->device));
@@ -480,29 +504,23 @@ int32_t eg_device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   c->timing_pending = true;
   c->last_n = n; c->last_first = first_index;
+  if (!pick) return EG_OK;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
 
-int32_t eg_device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed) {
+int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed, bool local_pick) {
   if (!c || !c->snap_valid || !d_packets || n_packets < 1 || !d_own_packet) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, c->out, c->last_n, c->last_first, nullptr);
+  int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, c->out, c->last_n, c->last_first,
+                               local_pick && n_packets == 1 && c->last_n > 0, nullptr);
   if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   lr = launch_stalled_tables(c->d_snap, nullptr);
   if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
-
-int32_t eg_device_step(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, uint32_t replay_period, uint64_t noise_seed) {
-  if (!c) return EG_ERR_BAD_ARG;
-  int rc = ensure_packet(c);
-  if (rc != EG_OK) return rc;
-  rc = eg_device_rollout(c, seed, first_index, n, replay_period, c->d_packet);
-  if (rc != EG_OK) return rc;
-  return eg_device_apply(c, c->d_packet, 1, c->d_packet, noise_seed);
-}
+}  // namespace
 
 int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
   if (!c || !p || !c->snap_valid) { set_error("eg_policy_pull: push a policy first"); return EG_ERR_BAD_ARG; }

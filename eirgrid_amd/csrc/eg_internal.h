@@ -235,8 +235,9 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
 int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
 // `o`, n_local, first_index: the batch the own packet came from (the winner's record is kept when it is one of them)
+// local_pick: one packet, made by this device's last batch — the candidate record is built inside the kernel
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
-                        const DevOut& o, uint32_t n_local, uint64_t first_index, void* stream);
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180); filled in the kernels from

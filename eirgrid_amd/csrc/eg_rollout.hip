@@ -970,6 +970,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
 // accumulated in log space, as integers (Q32 fixed point), so the result does not depend on the order in which
 // episodes, workgroups or ranks contribute: one sum all-reduce of this buffer is the whole exchange.
 //   stats[0] episodes ok   [1] episodes failed   [2] episodes that qualify for contrast (learning.rs:160)
+//   stats[3] best score of the batch as a sortable integer (bits of the score + 1; one-GPU best pick, see k_apply_update)
 //   stats[8 + (y*61+a)]              Σ Q32 ln(penalty_factor)  over occurrences of a in year y that are absent from best
 //   stats[8 + 26*61 + (y*61+a)]      Σ Q32 ln(mild_penalty)    over right-action-wrong-slot occurrences (learning.rs:241-251)
 //   stats[8 + 2*26*61 + (y*15+s)]    number of deficit actions of slot s in year y absent from best_deficit_actions[y]
@@ -998,7 +999,9 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
     return;
   }
   const double score = rm::score(O.metrics(e));
-  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; }
+  // st[3]: the batch's best score as an integer that sorts like the score (scores are not negative; + 1 so that 0 means
+  // "no successful episode"): with one GPU k_apply_update finds the best episode from it without a kernel of its own
+  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
   const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
@@ -1564,7 +1567,7 @@ __device__ void chacha12_block(const uint32_t* key, unsigned long long counter, 
 // the statistics are summed here (integers: any order gives the same sum), the candidate records sit behind them.
 __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const uint8_t* packets, int n_cands, long long* zero_stats,
                                                       unsigned long long noise_seed, const uint8_t* out_base, uint32_t n_local,
-                                                      unsigned long long first_index) {
+                                                      unsigned long long first_index, int local_pick) {
   constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
   constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
   __shared__ uint32_t s_noise[kBlocks * 16];
@@ -1611,6 +1614,31 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     if (i < Y * NA) { const int y = i / NA, a = i - y * NA; w_in[k] = pol[y * snap::kPolRow + a]; pen_in[k] = (double)stat(kPen + i) + (double)stat(kMild + i); }
   }
   if (tid < Y * ND) { const int y = tid / ND, sl = tid - y * ND; dw_in = pol[y * snap::kPolRow + snap::kPolDw + sl]; dcnt_in = stat(kDcnt + tid); }
+  if (local_pick) {
+    // One GPU: the candidate record of the packet is made here instead of by k_pick_best (a launch of 5.5 us per step).
+    // The rollout epilogue left the batch's best score in statistics slot 3; the best episode is the lowest index that
+    // holds it (highest score, ties to the lowest index), its metrics and lists are copied behind the statistics.
+    UpdateCandidate* cw = reinterpret_cast<UpdateCandidate*>(const_cast<uint8_t*>(cands));
+    const DevOut O{const_cast<uint8_t*>(out_base)};
+    const unsigned long long key = reinterpret_cast<const unsigned long long*>(packets)[3];
+    if (tid == 0) s_winner = 0x7FFFFFFF;
+    __syncthreads();
+    if (key != 0ull)
+      for (uint32_t i = tid; i < n_local; i += 1024) {
+        const double sc = *O.score(i);
+        if (sc >= 0.0 && (unsigned long long)__double_as_longlong(sc) + 1ull == key) atomicMin(&s_winner, (int)i);
+      }
+    __syncthreads();
+    const int win = s_winner != 0x7FFFFFFF ? s_winner : -1;
+    if (tid == 0) { cw->score = win >= 0 ? *O.score(win) : -1.0; cw->index = win >= 0 ? (long long)(first_index + (unsigned long long)win) : -1ll; }
+    if (win >= 0) {
+      if (tid < 4) cw->metrics[tid] = O.metrics(win)[tid];
+      if (tid < EG_YEARS) { cw->n_run[tid] = O.n_run(win)[tid]; cw->n_def[tid] = O.n_def(win)[tid]; }
+      for (int i = tid; i < EG_RUN_CAP; i += 1024) cw->run_log[i] = O.run_log(win)[i];
+      for (int i = tid; i < EG_DEF_CAP; i += 1024) cw->def_log[i] = O.def_log(win)[i];
+    }
+    __syncthreads();      // the record is in place for every thread of this workgroup
+  }
   if (tid == 64) {
     st = *gstate;
     // the batch's candidate: highest score, ties to the lowest global index (eg_policy_apply_packet)
@@ -1775,12 +1803,11 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 #endif
   for (int i = tid; i < EG_STATS_LEN; i += 1024) zero_stats[i] = 0;
 #ifdef EG_STAMPS
-  __syncthreads();      // the unused statistics slots 3..7 carry the phase durations out (after the zeroing above)
+  __syncthreads();      // the unused statistics slots 4..7 carry the phase durations out (after the zeroing above)
   if (tid == 0) {
     const unsigned long long t_end = wall_clock64();
-    zero_stats[3] = (long long)(dbg_t[2] - dbg_t[0]);      // state, winner, noise key, noise blocks
-    zero_stats[4] = (long long)(dbg_t[3] - dbg_t[2]);      // contrast step on the main table
-    zero_stats[5] = (long long)(dbg_t[4] - dbg_t[3]);      // best-strategy bookkeeping (one thread)
+    zero_stats[4] = (long long)(dbg_t[2] - dbg_t[0]);      // (best pick,) state, winner, noise key, noise blocks
+    zero_stats[5] = (long long)(dbg_t[4] - dbg_t[2]);      // contrast step on the main table + best-strategy bookkeeping
     zero_stats[6] = (long long)(dbg_t[5] - dbg_t[4]);      // list copies / deficit contrast
     zero_stats[7] = (long long)(t_end - dbg_t[5]);         // row sums, derive_state, zeroing
   }
@@ -1826,9 +1853,10 @@ int launch_stalled_tables(uint8_t* d_snap, void* stream) {
   return (int)hipGetLastError();
 }
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
-                        const DevOut& o, uint32_t n_local, uint64_t first_index, void* stream) {
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream) {
   hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, (const uint8_t*)d_packets, n_packets,
-                     d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, n_local, (unsigned long long)first_index);
+                     d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, n_local, (unsigned long long)first_index,
+                     local_pick ? 1 : 0);
   return (int)hipGetLastError();
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {

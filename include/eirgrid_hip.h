@@ -164,6 +164,8 @@ int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
  * a torch tensor): integer sums that do not depend on episode / workgroup / rank order, so ONE sum all-reduce over
  * RCCL is the whole exchange; eg_policy_apply_reduced then applies them on the host.  Layout:
  *   [0] episodes ok  [1] episodes failed  [2] episodes that qualify for contrast learning (learning.rs:160)
+ *   [3] NOT a sum: the batch's best score as a sortable integer (bit pattern of the score + 1, 0 = none), a maximum;
+ *       used on one GPU to find the best episode inside the update kernel, ignored by every update formula
  *   [8 + y*61 + a]               sum of Q32 ln(penalty_factor), learning.rs:232-239
  *   [8 + 26*61 + y*61 + a]       sum of Q32 ln(mild_penalty),   learning.rs:241-251
  *   [8 + 2*26*61 + y*15 + slot]  deficit actions absent from best_deficit_actions[y], learning.rs:346-352 */

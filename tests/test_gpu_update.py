@@ -71,6 +71,8 @@ def test_stats_kernel_vs_numpy(engine):
     np.testing.assert_allclose(st[8 + A:8 + 2 * A].reshape(26, 61) / 2.0**32, mild, rtol=0, atol=n * 100 * 2.0**-31)
     assert (st[8 + 2 * A:].reshape(26, 15) == dcnt).all()
     assert (pen <= 0).all() and pen.min() < 0
+    # slot 3: the best score of the batch as a sortable integer (bit pattern + 1), a maximum rather than a sum
+    assert int(st[3]) == int(np.float64(dev_scores.max()).view(np.int64)) + 1
     # the statistics are integer sums: launching the same batch again gives the identical buffer
     stats2 = torch.zeros_like(stats)
     engine.launch(999, 0, n); engine.update_stats(stats2.data_ptr()); engine.sync()
@@ -80,7 +82,9 @@ def test_stats_kernel_vs_numpy(engine):
     for f in (0, n // 2):
         t = torch.zeros_like(stats)
         engine.launch(999, f, n // 2); engine.update_stats(t.data_ptr()); engine.sync()
+        key = max(int(parts[3]), int(t[3]))
         parts += t
+        parts[3] = key
     assert torch.equal(parts, stats)
 
 
