@@ -79,12 +79,14 @@ def exchange_packet_raw(packet, dist=None):
     if dist.get_backend() == "gloo":          # CPU rehearsal of the same exchange (tests; no RCCL involved)
         host = packet.cpu()
         stats = host[:nstat].view(torch.int64).clone()
+        stats[3] = 0                                            # slot 3 is a maximum (best-score key), not a sum: unused here
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         mine = host[nstat:].clone()
         gathered = [torch.empty_like(mine) for _ in range(ws)]
         dist.all_gather(gathered, mine)
         return stats.numpy().copy(), torch.stack(gathered).numpy()
     stats = packet[:nstat].view(torch.int64)
+    stats[3] = 0                                                # slot 3 is a maximum (best-score key), not a sum: unused here
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)                # the one all-reduce of the update (RCCL over xGMI)
     both = torch.empty(nstat + ws * N.CANDIDATE_BYTES, dtype=torch.uint8, device=packet.device)
     dist.all_gather_into_tensor(both[nstat:], packet[nstat:].contiguous())
