@@ -192,7 +192,13 @@ class BatchTrainer:
                 self.eng.device_rollout(self.seed, first, self.n, self.replay_period, self.packet.data_ptr())
                 # the one collective of the update (RCCL over xGMI): every rank receives every rank's 32 KB packet; the
                 # statistics are integers, so summing them inside k_apply_update is the all-reduce
-                self.dist.all_gather_into_tensor(self.gathered, self.packet)
+                if self.dist.get_backend() == "gloo":      # rehearsal without RCCL: the same exchange through the host
+                    mine = self.packet.cpu()
+                    parts = [self.torch.empty_like(mine) for _ in range(self.ws)]
+                    self.dist.all_gather(parts, mine)
+                    self.gathered.copy_(self.torch.cat(parts))
+                else:
+                    self.dist.all_gather_into_tensor(self.gathered, self.packet)
                 self.eng.device_apply(self.gathered.data_ptr(), self.ws, self.packet.data_ptr(), noise)
             self.step_index += 1
             return None

@@ -398,3 +398,44 @@ def test_best_run_record_follows_the_best_episode(engine, world, tmp_path):
             fresh.close()
     finally:
         dev.close()
+
+
+def test_device_resident_replicas_of_two_processes_stay_identical():
+    """Two processes (two ranks sharing cuda:0, gloo standing in for RCCL) run the device-resident multi-rank step —
+    eg_device_rollout of the own shard, exchange of the 32 KB packets, eg_device_apply on both packets — and the
+    host-driven step on the same shards: after 8 steps all four policies must be the same, bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, hashlib
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from eirgrid_amd import synthetic_world
+from eirgrid_amd.engine import ActionWeights, Engine
+from eirgrid_amd.parallel import BatchTrainer
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+eng = Engine(synthetic_world(), device=0)
+out = []
+for resident in (True, False):
+    pol = ActionWeights()
+    tr = BatchTrainer(eng, pol, 96, 2024, rank, 2, dist, replay_fraction=0.25, device_resident=resident)
+    for _ in range(8): tr.step()
+    tr.sync()
+    w, dw, _ = pol.tables()
+    out.append(hashlib.sha256(w.tobytes() + dw.tobytes() + bytes(sum(pol.lists(0), []))).hexdigest() + ":%%d:%%d" %% (pol.get("iteration_count"), pol.get("iterations_without_improvement")))
+open(os.path.join(%r, "gpurun_out", "_two_rank_resident_%%d.txt" %% rank), "w").write(out[0] + " " + out[1])
+dist.barrier()
+dist.destroy_process_group()
+""" % (root, root)
+    script = os.path.join(root, "gpurun_out", "_two_rank_resident.py")
+    os.makedirs(os.path.dirname(script), exist_ok=True)
+    open(script, "w").write(code)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29544", script]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    res = [open(os.path.join(root, "gpurun_out", "_two_rank_resident_%d.txt" % k)).read().split() for k in (0, 1)]
+    assert res[0][0] == res[0][1] == res[1][0] == res[1][1], res
+    assert res[0][0].split(":")[1] == str(8 * 2 * 96)
