@@ -712,6 +712,10 @@ __device__ __forceinline__ YearSums year_sums_init_current() {
 //   protocol: episode wave writes cmd[seq & 1] and meets the helpers at a barrier; helper h evaluates chunk h and
 //   publishes {result, flag = seq}; the episode wave reads a helper's result only if that chunk's bound still reaches
 //   the best score, after spinning on its flag.  The next barrier cannot complete before every helper is back.
+// The helper reads the episode's generator list (sl.gpk) while the episode wave may already be appending the next
+// generator: it masks what lies behind the count it was given (chunk_product_latency<true>).  At the end of a year it
+// also keeps the year's starting sums ahead of the episode wave (kCmdYear: the sums of the year after next are started
+// over the lists as they are, the next year's — started a year ago — only receive what was added since).
 __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h) {
   const double size_factor = T.size_factor;
   PrefixCache cache = {0.0, -1, 0};
