@@ -1,20 +1,37 @@
 #!/usr/bin/env python3
 """Headline benchmark: full 26-year episodes/s of the rollout hot path on N MI355X (BASELINE.json `metric`).
 
-A step = one pass of the hot path over one batch, with the policy resident on the device: rollout of `--episodes`
-episodes per GPU against the current policy (k_rollout, batch-update statistics in its epilogue), best-episode pick
-(k_pick_best), when N > 1 the per-update exchange (ONE RCCL all-gather of every rank's 32 KB update packet), the batch
-update itself (k_apply_update) and the stalled-sampler tables (k_stalled_tables) — stream-ordered launches, no host
-synchronisation inside the timed region.  Inputs (world tables, policy) are resident in HBM when the timed region starts.
-Weak scaling: every rank runs `--episodes` episodes per step with streams keyed by global episode index.
+Workload (default, N = 1) = BASELINE configs[2] as SURVEY.md §8(d) defines it: 16 384 parallel 2025-2050 episodes per
+batch, every 10th episode (by global index) replaying the best strategy ("experience replay": force_best_actions,
+sampling.rs:78-145), the rest sampling from the policy; the best strategy the first batch meets is config 1's episode
+(seed 12345, index 0).  With N > 1 every rank runs that batch size on its own shard of the global index range
+(configs[3]: 8 x 16 384 = 131 072 episodes per update) and the update needs ONE collective.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+A batch pass = the whole hot path with the policy resident on the device: k_rollout (the episodes + the batch-update
+statistics in its epilogue), when N > 1 k_pick_best + ONE RCCL all-gather of every rank's 32 KB update packet, k_apply_update
+(the batch form of the reference's write-locked update, multi_simulation.rs:494-508), k_stalled_tables — stream-ordered
+launches, no host synchronisation, world tables and policy resident in HBM before the timed region starts.
+A STEP = `batches_per_step` consecutive batch passes; the number is chosen once, from a calibration of untimed passes,
+so that the K timed steps last at least --min-seconds (0.5 s) — `steps`, `warmup` are the K, W of the command line,
+`ms_per_step` is per step, `ms_per_batch` per pass.
+
+Reference semantics kept: a replay episode records and applies every action twice, so once a replay
+episode becomes the best strategy the replayed lists — and the generators each replay episode places — double.  The
+line reports what the loop did: `config.replay` (generators per replay / seeded episode, best-list length) and
+`config.episodes_failed` (EG_EP_OVERFLOW etc.; failed episodes are NOT counted in `value`).
+
+The line also carries `config1` (BASELINE configs[1]: 1 024 episodes per batch, no replay, its own timed region),
+`roofline` and `cpu_baseline` (N = 1).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
+import math
 import os
 import subprocess
 import sys
@@ -25,6 +42,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable)
+CUS, SIMDS_PER_CU = 256, 4
 
 
 def host_cores() -> int:
@@ -39,20 +57,46 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def pmc_traffic(episodes: int):
-    """HBM bytes per k_rollout launch from the newest committed PMC profile for this batch size (profiles/*pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, gfx950 correction applied) or None.
-    Counters cannot be collected from inside the process, so the number comes from the committed profile of the same build."""
-    import glob
+def newest_profile(pattern: str, key: str, sub: str):
+    """(value, file name) of the newest committed profiles/<pattern> that has an entry for `sub` under `key`."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
-            cfg = json.load(open(path))["configs"].get(str(episodes))
-        except (OSError, ValueError, KeyError):
+            cfg = json.load(open(path))[key].get(sub)
+        except (OSError, ValueError, KeyError, AttributeError):
             continue
         if cfg:
-            best = float(cfg["hbm_bytes_per_launch"])
+            best = (cfg, os.path.basename(path))
     return best
+
+
+def pmc_traffic(workload: str):
+    """HBM bytes per k_rollout launch from the newest committed PMC profile of this workload (profiles/*pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, gfx950 correction applied), with the
+    kernel duration of those passes.  Counters cannot be collected from inside the process, so the numbers come from
+    the committed profile of the same build; None when there is none."""
+    hit = newest_profile("*pmc_hbm_traffic.json", "configs", workload)
+    if not hit:
+        return None
+    cfg, name = hit
+    rows = cfg.get("fetch_rows") or []
+    dur = sum(r["dur_ns"] for r in rows) / len(rows) * 1e-9 if rows else None
+    return {"bytes": float(cfg["hbm_bytes_per_launch"]), "kernel_s": dur, "profile": name}
+
+
+def sq_counters(workload: str):
+    """VALU-busy share of the launch from the newest committed SQ counter profile of this workload
+    (profiles/*sq_counters.json): SQ_ACTIVE_INST_VALU (quad-cycles summed over the SIMDs) x 4 / (SIMDs x launch cycles)."""
+    hit = newest_profile("*sq_counters.json", "runs", workload)
+    if not hit:
+        return None
+    run, name = hit
+    try:
+        clock_hz = float(run.get("clock_hz", 2.4e9))
+        busy = run["SQ_ACTIVE_INST_VALU"] * 4.0 / (CUS * SIMDS_PER_CU * run["duration_ns"] * 1e-9 * clock_hz)
+    except (KeyError, ZeroDivisionError):
+        return None
+    return {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / max(run.get("episodes_per_launch", 1), 1)}
 
 
 def cpu_baseline(world, seconds_budget: float = 20.0):
@@ -88,7 +132,7 @@ def cpu_baseline(world, seconds_budget: float = 20.0):
         list(ex.map(tab, chunks))
     t_tab = time.perf_counter() - t0
     return {"value": n_lit / t_lit, "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": f"{n_lit} literal-mode episodes (seeds 12345+e, same synthetic world), one per thread on {cores} threads, "
+            "sample": f"{n_lit} literal-mode episodes (seeds 12345+e, fresh policy, same synthetic world), one per thread on {cores} threads, "
                       f"{t_lit:.1f} s wall; tabled mode: {n_tab} episodes in {t_tab:.1f} s",
             "tabled_value": n_tab / t_tab,
             "note": "C restatement of the reference algorithm (oracle/eg_oracle.c), not the Rust/rayon binary"}
@@ -97,7 +141,6 @@ def cpu_baseline(world, seconds_budget: float = 20.0):
 def measured_peak():
     """Triad bandwidth measured on an MI355X of this pool (scripts/hbm_probe.py -> profiles/*hbm_probe.json), reported beside
     the datasheet peak that `frac` is priced against; None when no probe result is committed."""
-    import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_probe.json"))):
         try:
@@ -107,15 +150,77 @@ def measured_peak():
     return best
 
 
+def batch_census(eng, episodes, first, period, had_best):
+    """What the last batch did, from its records: episodes by status, generators per seeded / replay episode, the two
+    byte counts.  (One strided device-to-host copy per field; outside every timed region.)"""
+    import numpy as np
+    res = eng.fetch(episodes)
+    ok = res.status == 0
+    idx = np.arange(first, first + episodes)
+    rep = (idx % period == 0) if (period and had_best) else np.zeros(episodes, bool)
+    mean = lambda a: float(a.mean()) if a.size else None
+    return {"ok": int(ok.sum()), "overflow": int((res.status == -1).sum()), "other_failures": int((~ok & (res.status != -1)).sum()),
+            "replay_episodes": int(rep.sum()),
+            "generators_per_seeded_episode": mean(res.n_gens[ok & ~rep]), "generators_per_replay_episode": mean(res.n_gens[ok & rep]),
+            "chunks_per_search": float(res.n_chunks[ok].sum()) / max(float(res.n_gens[ok].sum()), 1.0),
+            "nominal_bytes": float(res.bytes_moved[ok].sum()), "touched_bytes": float(res.bytes_touched()[ok].sum())}
+
+
+def timed_loop(trainer, eng, fence, batches):
+    """`batches` batch passes between two fences; returns (seconds, k_rollout HIP-event milliseconds, launches)."""
+    eng.sync(); eng.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        trainer.step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms, n = eng.timing_read()
+    return elapsed, ms, n
+
+
+def roofline_object(workload, census, episodes, avg_kernel_s):
+    """`achieved` = bytes the implemented algorithm touches per launch / measured kernel time (the SURVEY formula with the
+    2601 x 8 B score field of every search replaced by the candidate records the branch-and-bound search requested);
+    `nominal_*` = the SURVEY §8(d) formula as written (it bills the field, which this kernel never reads);
+    `traffic` = HBM bytes per launch from the committed PMC profile of this workload; `hbm_frac_measured` = that traffic
+    over the kernel time of the same profiled launches over peak; `valu_busy` from the committed SQ counters.  `bound`
+    says what the counters say: the kernel is bound by VALU issue / latency of its serial episode waves, not by HBM."""
+    touched = census["touched_bytes"] * episodes / max(census["ok"], 1)
+    nominal = census["nominal_bytes"] * episodes / max(census["ok"], 1)
+    achieved = touched / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    tr, sq = pmc_traffic(workload), sq_counters(workload)
+    obj = {"bound": "valu-issue/latency (HBM roofline not the limiter: see hbm_frac_measured, valu_busy)",
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "peak_measured": measured_peak(), "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
+           "hbm_frac_measured": (tr["bytes"] / tr["kernel_s"] / 1e9 / HBM_PEAK_GBS) if tr and tr["kernel_s"] else None,
+           "valu_busy": sq["valu_busy"] if sq else None,
+           "kernel": "k_rollout", "avg_kernel_ms": avg_kernel_s * 1e3,
+           "touched_bytes_per_launch": touched, "touched_bytes_per_episode": touched / max(episodes, 1),
+           "nominal_bytes_per_launch": nominal, "nominal_frac": nominal / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else 0.0,
+           "chunks_per_search": census["chunks_per_search"],
+           "kernel_only_episodes_per_s": episodes / avg_kernel_s if avg_kernel_s > 0 else 0.0,
+           "profiles": {"traffic": tr["profile"] if tr else None, "sq": sq["profile"] if sq else None}}
+    return obj
+
+
+def workload_key(episodes: int, replay_fraction: float) -> str:
+    """Key of a workload in the committed profiles (profiles/*_pmc_hbm_traffic.json, *_sq_counters.json)."""
+    return f"{episodes}" if replay_fraction == 0.0 else f"{episodes}r{replay_fraction:g}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--episodes", type=int, default=1024, help="episodes per GPU per step (BASELINE configs[1] = 1024)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--episodes", type=int, default=16384, help="episodes per GPU per batch (BASELINE configs[2]/[3]: 16384; configs[1]: 1024)")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--replay-fraction", type=float, default=0.0, help="configs[2]: 0.1")
+    ap.add_argument("--replay-fraction", type=float, default=0.1, help="configs[2]: 0.1 (every 10th global index replays the best strategy); configs[1]: 0")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the K timed steps last at least this long (batches_per_step is sized for it)")
+    ap.add_argument("--batches-per-step", type=int, default=0, help="fix it instead of calibrating (0 = calibrate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config1", action="store_true", help="skip the second object (configs[1]: 1024 episodes, no replay)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-collectives", action="store_true",
@@ -150,7 +255,6 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")      # only matters for --force-collectives outside torchrun
         if args.backend == "nccl":
@@ -161,6 +265,12 @@ def main():
     world = synthetic_world()
     eng = Engine(world, device=local_rank)
     weights = ActionWeights()
+    if args.replay_fraction > 0.0:
+        # the replayed best-action list is config 1's episode (seed 12345, global index 0) — installed
+        # by the reference's own sequential update (multi_simulation.rs:494-508) of that one episode, on every rank alike
+        first = eng.run_iteration(0, weights, False, args.seed)
+        weights.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
+                              first.def_log[0, :first.n_def[0].sum()])
     trainer = BatchTrainer(eng, weights, args.episodes, args.seed, rank, world_size, dist if use_dist else None,
                            replay_fraction=args.replay_fraction, write_yearly=not args.no_yearly,
                            force_collectives=args.force_collectives)
@@ -170,49 +280,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def all_max(x: float) -> float:
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- calibration (untimed for the result): the loop's cost per batch changes while the first best strategies are
+    #      found (replay episodes grow, Q15), so it is taken from the LAST passes of 10 ----
+    bps = args.batches_per_step
+    calibration = 0
+    if bps <= 0:
+        for _ in range(8):
+            trainer.step()
+        el, _, _ = timed_loop(trainer, eng, fence, 2)
+        per_batch = all_max(el) / 2.0
+        calibration = 10
+        bps = int(min(256, max(1, math.ceil(args.min_seconds / max(args.steps, 1) / max(per_batch, 1e-6)))))
+    for _ in range(args.warmup * bps):
         trainer.step()
-    eng.sync(); eng.timing_reset()
-    fence()
     if saved_stdout is not None:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1); os.close(saved_stdout)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    failed_before = trainer.failed_episodes()
+    elapsed, kernel_ms, n_launch = timed_loop(trainer, eng, fence, args.steps * bps)
+    elapsed = all_max(elapsed)
+    failed = trainer.failed_episodes() - failed_before      # episodes of ALL ranks that did not finish (counted by the updates)
+    had_best = True      # (a best strategy exists from the first batch on)
+    last_first = (trainer.step_index - 1) * args.episodes * world_size + rank * args.episodes
+    census = batch_census(eng, args.episodes, last_first, trainer.replay_period, had_best)
     trainer.sync()                     # device-resident policy -> host copy (after the timed region)
-    kernel_ms, n_launch = eng.timing_read()
-    res = eng.fetch(args.episodes)
-    ok = int((res.status == 0).sum())
-    bytes_per_launch = float(res.bytes_moved.sum())
     avg_kernel_s = kernel_ms / max(n_launch, 1) * 1e-3
-    achieved = bytes_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
 
+    line = None
     if rank == 0:
-        total_eps = args.episodes * world_size * args.steps
+        batches = args.steps * bps
+        total_eps = args.episodes * world_size * batches - failed
+        cfg_name = ("BASELINE configs[2]" if world_size == 1 else f"BASELINE configs[3] at {world_size} GPUs") \
+            if (args.episodes == 16384 and abs(args.replay_fraction - 0.1) < 1e-12) else \
+            ("BASELINE configs[1]" if (args.episodes == 1024 and args.replay_fraction == 0.0 and world_size == 1) else "custom")
         line = {
             "metric": "26-year episodes/sec", "value": total_eps / elapsed, "unit": "episodes/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.episodes} parallel 2025-2050 episodes per GPU per step "
-                                   "(grid step + tabular policy sampling + batch policy update), synthetic world "
-                                   "S=130 settlements / G0=59 existing plant / P=200 coast points, fresh ActionWeights, seed 12345",
-                       "episodes_per_gpu_per_step": args.episodes, "replay_fraction": args.replay_fraction,
+            "batches_per_step": bps, "ms_per_batch": elapsed / batches * 1e3, "timed_region_s": elapsed, "calibration_batches": calibration,
+            "config": {"workload": f"{cfg_name}: {args.episodes} parallel 2025-2050 episodes per GPU per batch"
+                                   + (f", every {trainer.replay_period}th global index replaying the best strategy (experience replay, reference "
+                                      "semantics incl. its double recording, SURVEY Q15)" if trainer.replay_period else ", no replay")
+                                   + "; batch pass = rollout (grid step + tabular policy sampling) + batch policy update on the device; synthetic world "
+                                     "S=130 settlements / G0=59 existing plant / P=200 coast points, ActionWeights::new, seed 12345",
+                       "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction,
+                       "batches_timed": batches, "episodes_failed": failed,
                        "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one 32 KB all-gather per update "
                                       "(integer statistics summed in the update kernel)",
-                       "episodes_ok_last_batch": ok, "strategy_improvements": trainer.improvements},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "peak_measured": measured_peak(), "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.episodes), "kernel": "k_rollout",
-                         "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "bytes_per_episode": bytes_per_launch / max(args.episodes, 1),
-                         "kernel_only_episodes_per_s": args.episodes / avg_kernel_s if avg_kernel_s > 0 else 0.0},
+                       "last_batch": {k: census[k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
+                                                             "generators_per_seeded_episode", "generators_per_replay_episode")},
+                       "replay": {"best_list_len": int(sum(len(l) for l in weights.lists(0))),
+                                  "best_deficit_list_len": int(sum(len(l) for l in weights.lists(1)))},
+                       "strategy_improvements": trainer.improvements,
+                       "iterations_without_improvement": int(weights.get("iterations_without_improvement"))},
+            "roofline": roofline_object(workload_key(args.episodes, args.replay_fraction), census, args.episodes, avg_kernel_s),
         }
+    # ---- second object: BASELINE configs[1] (1024 episodes per batch, no replay), its own policy and timed region ----
+    if world_size == 1 and not args.no_config1 and not (args.episodes == 1024 and args.replay_fraction == 0.0):
+        w1 = ActionWeights()
+        t1 = BatchTrainer(eng, w1, 1024, args.seed, 0, 1, None, replay_fraction=0.0, write_yearly=not args.no_yearly)
+        for _ in range(8):
+            t1.step()
+        el, _, _ = timed_loop(t1, eng, fence, 8)
+        n1 = int(max(20, math.ceil(args.min_seconds / max(el / 8.0, 1e-6))))
+        f0 = t1.failed_episodes()
+        el, kms, nl = timed_loop(t1, eng, fence, n1)
+        f1 = t1.failed_episodes() - f0
+        c1 = batch_census(eng, 1024, (t1.step_index - 1) * 1024, 0, True)
+        t1.sync()
+        line["config1"] = {"workload": "BASELINE configs[1]: 1024 parallel episodes per batch, no replay; batch pass = rollout + batch policy update",
+                           "value": (1024 * n1 - f1) / el, "unit": "episodes/s", "batches_timed": n1, "timed_region_s": el,
+                           "ms_per_batch": el / n1 * 1e3, "episodes_failed": f1,
+                           "roofline": roofline_object(workload_key(1024, 0.0), c1, 1024, kms / max(nl, 1) * 1e-3)}
+    if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(world)
         print(json.dumps(line), flush=True)

@@ -15,7 +15,8 @@ STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
 CANDIDATE_BYTES = 8 + 8 + 32 + 4 * YEARS + 4 * YEARS + RUN_CAP + DEF_CAP
 PACKET_BYTES = 8 * STATS_LEN + CANDIDATE_BYTES
 
-EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+EG_OK, EG_ERR_NO_DEVICE, EG_ERR_BAD_ARG, EG_ERR_HIP, EG_ERR_UNSUPPORTED, EG_ERR_NOMEM, EG_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+EG_EP_OK, EG_EP_OVERFLOW, EG_EP_NO_LOCATION, EG_EP_INTERNAL = 0, -1, -2, -3
 
 # EIRGRID_LIB selects another build of the same library (only used for the -DEG_STAMPS diagnostic build)
 LIB_PATH = os.environ.get("EIRGRID_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeirgrid_hip.so")
@@ -50,13 +51,14 @@ class EgPolicySnapshot(C.Structure):
 class EgEpisodeOut(C.Structure):
     _fields_ = [("metrics", _dp), ("yearly", _dp), ("status", _i32p), ("n_run", _i32p), ("n_def", _i32p), ("n_act", _i32p),
                 ("run_log", _u8p), ("def_log", _u8p), ("act_log", _u8p), ("n_gens", _i32p), ("gen_cell", _u16p),
-                ("gen_pack", _u16p), ("n_offsets", _i32p), ("off_pack", _u16p), ("n_draws", _u64p), ("bytes_moved", _dp)]
+                ("gen_pack", _u16p), ("n_offsets", _i32p), ("off_pack", _u16p), ("n_draws", _u64p), ("bytes_moved", _dp),
+                ("n_chunks", _u32p)]
 
 
 # every symbol include/eirgrid_hip.h declares
 EXPORTS = [
-    "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
-    "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
+    "eg_build_hash", "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
+    "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_last_batch_size", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
     "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_place", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
     "eg_policy_push", "eg_device_rollout", "eg_device_apply", "eg_device_step", "eg_policy_pull",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
@@ -68,6 +70,21 @@ EXPORTS = [
 _lib = None
 
 
+def source_hash() -> str:
+    """The hash csrc/Makefile stamps into the library (eg_build_hash): sha256 over the sources it is built from, in the
+    Makefile's order (make's $(sort) = byte order of the relative paths)."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    rel = [os.path.basename(f) for pat in ("*.hip", "*.cpp", "*.h") for f in glob.glob(os.path.join(csrc, pat))]
+    rel += ["../../include/" + os.path.basename(f) for f in glob.glob(os.path.join(csrc, "..", "..", "include", "*.h"))]
+    rel = sorted(set(rel + ["Makefile"]) - {"eg_build_hash.cpp"}, key=lambda r: r.encode())
+    h = hashlib.sha256()
+    for r in rel:
+        h.update(open(os.path.join(csrc, r), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -76,6 +93,11 @@ def lib():
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  eirgrid_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    if not os.environ.get("EIRGRID_LIB"):      # a stale or mixed binary (e.g. a prebuilt .so shipped next to edited sources) fails loudly
+        L.eg_build_hash.restype = C.c_char_p
+        built, tree = L.eg_build_hash().decode(), source_hash()
+        if built != tree:
+            raise ImportError(f"{LIB_PATH} was built from other sources (library {built}, tree {tree}): run `make -C eirgrid_amd/csrc`")
     L.eg_last_error.restype = C.c_char_p
     L.eg_device_count.restype = C.c_int32
     L.eg_create.restype = C.c_void_p
@@ -92,6 +114,8 @@ def lib():
     L.eg_rollout_launch_update.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, _u8p, C.c_void_p]
     L.eg_sync.restype = C.c_int32
     L.eg_sync.argtypes = [C.c_void_p]
+    L.eg_last_batch_size.restype = C.c_uint32
+    L.eg_last_batch_size.argtypes = [C.c_void_p]
     L.eg_fetch.restype = C.c_int32
     L.eg_fetch.argtypes = [C.c_void_p, C.POINTER(EgEpisodeOut)]
     L.eg_timing_reset.restype = C.c_int32

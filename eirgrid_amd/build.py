@@ -9,7 +9,8 @@ LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeirgrid_hip.s
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+    # `negative`: the two fault-injection builds the GPU parity tests load through EIRGRID_LIB (csrc/Makefile)
+    cmd = ["make", "-C", _CSRC, "all", "negative"] + (["-B"] if force else [])
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout[-4000:]); print(r.stderr[-4000:])

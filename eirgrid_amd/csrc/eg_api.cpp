@@ -66,11 +66,16 @@ struct eg_ctx {
   uint32_t out_cap = 0, last_n = 0;
   uint64_t last_first = 0;      // global index of the first episode of the last batch
   uint8_t* d_mask = nullptr; uint32_t mask_cap = 0;
-  // timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // timing: a ring of event pairs riding on the rollout dispatches.  A pair is only waited for when the ring comes round to
+  // it again (kTimingRing launches later: long finished) or when the caller reads the timing — never inside a training step.
+  static constexpr int kTimingRing = 256;
+  hipEvent_t ev0[kTimingRing] = {}, ev1[kTimingRing] = {};
+  int ring_head = 0, ring_pending = 0;      // next pair to use; pairs recorded and not yet collected (the oldest is head - pending)
   double total_ms = 0.0; int32_t n_launches = 0;
-  bool timing_pending = false;
+  // eg_place: device buffers kept between calls
+  uint16_t* d_place_cells = nullptr; int32_t* d_place_cell = nullptr; double* d_place_score = nullptr;
   uint32_t push_iteration_count = 0;     // iteration counter written into the device state by the next upload
+  uint32_t push_failed = 0;              // ... and the failed-episode counter
   uint32_t pulled_improvements = 0;      // on-device improvement log entries already appended to a host policy
   // eg_train_step / eg_device_step: library-owned update packet (device) and its pinned host copy
   uint8_t* d_packet = nullptr; uint8_t* h_packet = nullptr;
@@ -101,14 +106,25 @@ int ensure_outputs(eg_ctx* c, uint32_t n) {
   return EG_OK;
 }
 
-int collect_timing(eg_ctx* c) {
-  if (!c->timing_pending) return EG_OK;
-  EG_HIP(hipEventSynchronize(c->ev1));
-  float ms = 0.f;
-  EG_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  c->total_ms += double(ms); c->n_launches += 1; c->timing_pending = false;
+// collects the oldest `count` recorded pairs (all of them when count < 0)
+int collect_timing(eg_ctx* c, int count = -1) {
+  if (count < 0 || count > c->ring_pending) count = c->ring_pending;
+  for (; count > 0; --count) {
+    const int i = (c->ring_head - c->ring_pending + 2 * eg_ctx::kTimingRing) % eg_ctx::kTimingRing;
+    EG_HIP(hipEventSynchronize(c->ev1[i]));
+    float ms = 0.f;
+    EG_HIP(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+    c->total_ms += double(ms); c->n_launches += 1; c->ring_pending -= 1;
+  }
   return EG_OK;
 }
+// the event pair of the next rollout launch (frees the oldest one first when the ring is full)
+int next_timing_slot(eg_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+  if (c->ring_pending == eg_ctx::kTimingRing) { int rc = collect_timing(c, 1); if (rc != EG_OK) return rc; }
+  *e0 = c->ev0[c->ring_head]; *e1 = c->ev1[c->ring_head];
+  return EG_OK;
+}
+void timing_launched(eg_ctx* c) { c->ring_head = (c->ring_head + 1) % eg_ctx::kTimingRing; c->ring_pending += 1; }
 
 }  // namespace
 
@@ -199,7 +215,8 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     }
   }
   D.size_factor = H.size_factor; D.n_existing = world->n_existing;
-  if (rc == EG_OK && (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess)) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
+  for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
+    if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
   if (rc == EG_OK) {
     if (hipMalloc((void**)&c->d_snap, snap::total) != hipSuccess || hipHostMalloc((void**)&c->h_snap, snap::total) != hipSuccess) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
@@ -220,8 +237,13 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_packet) (void)hipFree(c->d_packet);
   if (c->h_packet) (void)hipHostFree(c->h_packet);
   free_outputs(c);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (int i = 0; i < eg_ctx::kTimingRing; ++i) {
+    if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+    if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+  }
+  if (c->d_place_cells) (void)hipFree(c->d_place_cells);
+  if (c->d_place_cell) (void)hipFree(c->d_place_cell);
+  if (c->d_place_score) (void)hipFree(c->d_place_score);
   delete c;
 }
 
@@ -291,7 +313,7 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
     DevState st{};
     st.learning_rate = s->learning_rate; st.exploration_rate = s->exploration_rate;
     for (int i = 0; i < 4; ++i) st.best_metrics[i] = s->has_best ? s->best_metrics[i] : 0.0;
-    st.stall = s->iterations_without_improvement; st.iteration_count = c->push_iteration_count;
+    st.stall = s->iterations_without_improvement; st.iteration_count = c->push_iteration_count; st.failed_total = c->push_failed;
     st.has_best = s->has_best ? 1 : 0; st.has_cw = s->count_weights ? 1 : 0; st.has_lists = have_lists ? 1 : 0;
     rm::derive_state(st);
     std::memcpy(h + snap::state, &st, sizeof(st));
@@ -322,11 +344,12 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
     EG_HIP(hipMemcpy(c->d_mask, replay_mask, n, hipMemcpyHostToDevice));
     d_mask = c->d_mask;
   }
-  rc = collect_timing(c);
+  hipEvent_t e0, e1;
+  rc = next_timing_slot(c, &e0, &e1);
   if (rc != EG_OK) return rc;
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes, e0, e1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  c->timing_pending = true;
+  timing_launched(c);
   c->last_n = n; c->last_first = first_index;
   return EG_OK;
 }
@@ -342,12 +365,13 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
     EG_HIP(hipMemcpyAsync(c->d_mask, replay_mask, n, hipMemcpyHostToDevice, nullptr));
     d_mask = c->d_mask;
   }
-  rc = collect_timing(c);
+  hipEvent_t e0, e1;
+  rc = next_timing_slot(c, &e0, &e1);
   if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes, c->ev0, c->ev1);
+  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes, e0, e1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  c->timing_pending = true;
+  if (n > 0) timing_launched(c);      // (launch_rollout does not launch an empty batch)
   c->last_n = n; c->last_first = first_index;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -387,24 +411,39 @@ int fetch_records(const uint8_t* d_base, size_t N, eg_episode_out* o) {
   EG_GET(n_offsets, 1, int32_t); EG_GET(off_pack, EG_MAX_OFFSETS, uint16_t);
   EG_GET(bytes_moved, 1, double);
   EG_GET(n_draws, 1, uint64_t);
+  EG_GET(n_chunks, 1, uint32_t);
 #undef EG_GET
   return EG_OK;
 }
 }  // namespace
+
+namespace {
+// an episode that ended with EG_EP_INTERNAL is a defect of the kernel's helper-wave protocol, not a property of the input
+int check_internal(const int32_t* status, size_t n) {
+  if (!status) return EG_OK;
+  for (size_t i = 0; i < n; ++i)
+    if (status[i] == EG_EP_INTERNAL) { set_error("k_rollout: helper-wave protocol timed out in episode " + std::to_string(i) + " (EG_EP_INTERNAL)"); return EG_ERR_INTERNAL; }
+  return EG_OK;
+}
+}  // namespace
+
+uint32_t eg_last_batch_size(const eg_ctx* c) { return c ? c->last_n : 0u; }
 
 int32_t eg_fetch(eg_ctx* c, eg_episode_out* o) {
   if (!c || !o) return EG_ERR_BAD_ARG;
   int rc = eg_sync(c);
   if (rc != EG_OK) return rc;
   if (c->last_n == 0) return EG_OK;
-  return fetch_records(c->out.base, c->last_n, o);
+  rc = fetch_records(c->out.base, c->last_n, o);
+  return rc != EG_OK ? rc : check_internal(o->status, c->last_n);
 }
 
 int32_t eg_fetch_record(eg_ctx* c, uint32_t episode, eg_episode_out* o) {
   if (!c || !o || episode >= c->last_n) { set_error("eg_fetch_record: bad argument"); return EG_ERR_BAD_ARG; }
   int rc = eg_sync(c);
   if (rc != EG_OK) return rc;
-  return fetch_records(c->out.base + size_t(episode) * rec::stride, 1, o);
+  rc = fetch_records(c->out.base + size_t(episode) * rec::stride, 1, o);
+  return rc != EG_OK ? rc : check_internal(o->status, 1);
 }
 
 int32_t eg_fetch_best_run(eg_ctx* c, eg_episode_out* o, int32_t* state) {
@@ -418,14 +457,13 @@ int32_t eg_fetch_best_run(eg_ctx* c, eg_episode_out* o, int32_t* state) {
   return fetch_records(c->d_snap + snap::best_rec, 1, o);
 }
 
+namespace { int ensure_packet(eg_ctx* c); }
 int32_t eg_train_step(eg_ctx* c, eg_policy* p, const eg_opts* o, uint64_t seed, uint64_t first_index, uint32_t n,
                       const uint8_t* replay_mask, uint64_t noise_seed) {
   if (!c || !p) { set_error("eg_train_step: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  if (!c->d_packet) {
-    EG_HIP(hipMalloc((void**)&c->d_packet, EG_PACKET_BYTES));
-    EG_HIP(hipHostMalloc((void**)&c->h_packet, EG_PACKET_BYTES));
-  }
+  int prc = ensure_packet(c);
+  if (prc != EG_OK) return prc;
   eg_policy_snapshot snap;
   int rc = eg_policy_snapshot_view(p, &snap);
   if (rc != EG_OK) return rc;
@@ -443,6 +481,7 @@ namespace {
 int ensure_packet(eg_ctx* c) {
   if (c->d_packet) return EG_OK;
   EG_HIP(hipMalloc((void**)&c->d_packet, EG_PACKET_BYTES));
+  EG_HIP(hipMemset(c->d_packet, 0, EG_PACKET_BYTES));      // the rollout epilogue ADDS to the statistics
   EG_HIP(hipHostMalloc((void**)&c->h_packet, EG_PACKET_BYTES));
   return EG_OK;
 }
@@ -453,14 +492,22 @@ int32_t eg_policy_push(eg_ctx* c, const eg_policy* p, const eg_opts* o) {
   eg_policy_snapshot snap;
   int rc = eg_policy_snapshot_view(p, &snap);
   if (rc != EG_OK) return rc;
-  c->push_iteration_count = p->iteration_count;
+  c->push_iteration_count = p->iteration_count; c->push_failed = p->failed_episodes;
   rc = eg_upload_snapshot(c, &snap, o);
-  c->push_iteration_count = 0;
+  c->push_iteration_count = 0; c->push_failed = 0;
   if (rc != EG_OK) return rc;
   c->pulled_improvements = 0;
   rc = ensure_packet(c);
   if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(c->d_packet, 0, EG_PACKET_BYTES, nullptr));
+  {  // the kept record of the best episode (eg_fetch_best_run) survives a push only when it is the pushed policy's best
+     // strategy (checkpoint / resume on the same context); a record left by another policy is dropped
+    uint32_t word = 0; double m[4] = {0, 0, 0, 0};
+    EG_HIP(hipMemcpy(&word, c->d_snap + snap::best_rec_state, sizeof(word), hipMemcpyDeviceToHost));
+    if (word == 1u) EG_HIP(hipMemcpy(m, c->d_snap + snap::best_rec + rec::metrics, sizeof(m), hipMemcpyDeviceToHost));
+    const bool same = word == 1u && p->has_best && std::memcmp(m, p->best_metrics.data(), sizeof(m)) == 0;
+    if (word != 0u && !same) EG_HIP(hipMemsetAsync(c->d_snap + snap::best_rec_state, 0, sizeof(uint32_t), nullptr));
+  }
   // main weights at the last improvement travel with the policy
   if (p->has_best_weights) EG_HIP(hipMemcpyAsync(c->d_snap + snap::best_w, p->best_w.data(), sizeof(double) * EG_YEARS * EG_N_ACTIONS, hipMemcpyHostToDevice, nullptr));
   EG_HIP(hipStreamSynchronize(nullptr));      // p->best_w is pageable host memory
@@ -497,12 +544,13 @@ int device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, u
   EG_HIP(hipSetDevice(c->device));
   int rc = ensure_outputs(c, n);
   if (rc != EG_OK) return rc;
-  rc = collect_timing(c);
+  hipEvent_t e0, e1;
+  rc = next_timing_slot(c, &e0, &e1);
   if (rc != EG_OK) return rc;
   int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, nullptr, replay_period, (long long*)d_packet, nullptr,
-                          n <= c->helper_max_episodes, c->ev0, c->ev1);
+                          n <= c->helper_max_episodes, e0, e1);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  c->timing_pending = true;
+  timing_launched(c);
   c->last_n = n; c->last_first = first_index;
   if (!pick) return EG_OK;
   lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
@@ -535,7 +583,7 @@ int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
     for (int a = 0; a < EG_N_ACTIONS; ++a) p->w[y][a] = row[a];
     for (int i = 0; i < EG_N_DEFICIT; ++i) p->dw[y][i] = row[snap::kPolDw + i];
   }
-  p->stall = st.stall; p->iteration_count = st.iteration_count;
+  p->stall = st.stall; p->iteration_count = st.iteration_count; p->failed_episodes = st.failed_total;
   if (st.n_improvements > 0) {      // at least one on-device improvement since the push: the best strategy is the device's
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = st.best_metrics[i];
     const int32_t* off = reinterpret_cast<const int32_t*>(h.data() + snap::best_off);
@@ -622,17 +670,18 @@ int32_t eg_place(eg_ctx* c, int32_t gen_type, int32_t year_index, const uint16_t
   }
   for (int i = 0; i < n_extra; ++i) if (extra_cells[i] >= EG_CELLS) { set_error("eg_place: cell out of range"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
-  uint16_t* d_cells = nullptr; int32_t* d_cell = nullptr; double* d_score = nullptr;
-  EG_HIP(hipMalloc((void**)&d_cells, sizeof(uint16_t) * (n_extra > 0 ? n_extra : 1)));
-  EG_HIP(hipMalloc((void**)&d_cell, sizeof(int32_t)));
-  EG_HIP(hipMalloc((void**)&d_score, sizeof(double)));
+  if (!c->d_place_cells) {      // kept for the life of the context
+    EG_HIP(hipMalloc((void**)&c->d_place_cells, sizeof(uint16_t) * EG_MAX_GENS));
+    EG_HIP(hipMalloc((void**)&c->d_place_cell, sizeof(int32_t)));
+    EG_HIP(hipMalloc((void**)&c->d_place_score, sizeof(double)));
+  }
+  uint16_t* d_cells = c->d_place_cells; int32_t* d_cell = c->d_place_cell; double* d_score = c->d_place_score;
   if (n_extra) EG_HIP(hipMemcpy(d_cells, extra_cells, sizeof(uint16_t) * n_extra, hipMemcpyHostToDevice));
   int lr = launch_place(c->dev, gen_type, year_index, d_cells, n_extra, d_cell, d_score, nullptr);
   if (lr != 0) { set_error(std::string("k_place launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   int32_t cell = -1; double score = 0.0;
   EG_HIP(hipMemcpy(&cell, d_cell, sizeof(cell), hipMemcpyDeviceToHost));
   EG_HIP(hipMemcpy(&score, d_score, sizeof(score), hipMemcpyDeviceToHost));
-  (void)hipFree(d_cells); (void)hipFree(d_cell); (void)hipFree(d_score);
   if (out_cell) *out_cell = cell;
   if (out_score) *out_score = score;
   return EG_OK;

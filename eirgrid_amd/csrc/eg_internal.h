@@ -125,7 +125,7 @@ struct DevState {
   uint32_t heur_min, heur_max;                                // sampling.rs:425-427
   uint32_t n_improvements;     // improvements installed by on-device updates since the last upload (log entries written)
   int32_t improved_last;       // the last on-device update installed a new best strategy
-  uint32_t pad;
+  uint32_t failed_total;       // episodes (all ranks) that ended with a status other than EG_EP_OK, as counted by the updates
 };
 static_assert(sizeof(DevState) % 8 == 0, "state layout");
 struct DevImprovement { double score, metrics[4]; uint32_t iteration, pad; };   // on-device improvement log entry
@@ -196,7 +196,8 @@ constexpr size_t bytes_moved = 40;                    // f64
 constexpr size_t n_draws = 48;                        // u64
 constexpr size_t status = 56;                         // i32
 constexpr size_t n_gens = 60;                         // i32
-constexpr size_t n_offsets = 64;                      // i32 (+4 pad)
+constexpr size_t n_offsets = 64;                      // i32
+constexpr size_t n_chunks = 68;                       // u32: chunks of candidate records the placement searches requested
 constexpr size_t n_run = 72;                          // i32 [26]
 constexpr size_t n_def = n_run + 4 * EG_YEARS;
 constexpr size_t n_act = n_def + 4 * EG_YEARS;
@@ -216,7 +217,7 @@ struct DevOut {
   uint8_t* base;
 #define EG_REC(name, type) EG_HD type* name(uint32_t e) const { return reinterpret_cast<type*>(base + size_t(e) * rec::stride + rec::name); }
   EG_REC(metrics, double) EG_REC(score, double) EG_REC(bytes_moved, double) EG_REC(n_draws, unsigned long long)
-  EG_REC(status, int32_t) EG_REC(n_gens, int32_t) EG_REC(n_offsets, int32_t)
+  EG_REC(status, int32_t) EG_REC(n_gens, int32_t) EG_REC(n_offsets, int32_t) EG_REC(n_chunks, uint32_t)
   EG_REC(n_run, int32_t) EG_REC(n_def, int32_t) EG_REC(n_act, int32_t) EG_REC(yearly, double)
   EG_REC(run_log, uint8_t) EG_REC(def_log, uint8_t) EG_REC(act_log, uint8_t)
   EG_REC(gen_cell, uint16_t) EG_REC(gen_pack, uint16_t) EG_REC(off_pack, uint16_t)

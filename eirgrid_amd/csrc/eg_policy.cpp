@@ -153,6 +153,7 @@ int32_t eg_policy_set_tables(eg_policy* p, const double* w, const double* dw, co
 }
 // scalar codes: 0 learning_rate 1 exploration_rate 2 iterations_without_improvement 3 iteration_count 4 has_best
 //               5..8 best_metrics 9 has_best_actions 10 has_best_deficit_actions 11 has_count_weights
+//               12 improvement_history length (read only) 13 failed_episodes
 double eg_policy_get_scalar(const eg_policy* p, int32_t which) {
   switch (which) {
     case 0: return p->learning_rate; case 1: return p->exploration_rate; case 2: return double(p->stall);
@@ -161,6 +162,7 @@ double eg_policy_get_scalar(const eg_policy* p, int32_t which) {
     case 9: return p->has_best_actions ? 1.0 : 0.0; case 10: return p->has_best_deficit ? 1.0 : 0.0;
     case 11: return p->has_cw ? 1.0 : 0.0;
     case 12: return double(p->improvement_history.size());
+    case 13: return double(p->failed_episodes);
     default: return 0.0;
   }
 }
@@ -171,6 +173,7 @@ int32_t eg_policy_set_scalar(eg_policy* p, int32_t which, double v) {
     case 5: case 6: case 7: case 8: p->best_metrics[which - 5] = v; break;
     case 9: p->has_best_actions = v != 0.0; break; case 10: p->has_best_deficit = v != 0.0; break;
     case 11: p->has_cw = v != 0.0; break;
+    case 13: p->failed_episodes = uint32_t(v); break;
     default: return EG_ERR_BAD_ARG;
   }
   return EG_OK;
@@ -271,9 +274,10 @@ int32_t eg_policy_apply_episode(eg_policy* p, const double metrics[4], const int
 
 // Batch form of the three steps above ("reduced mode").  All episodes of the batch were sampled from
 // the same snapshot, so they are all contrasted against the best strategy of that snapshot; their multiplicative
-// nudges were summed in log space on the device (Q32 integers) and are applied once, with the clamps applied after
-// accumulation.  Then the batch's best episode competes for the best slot, then the deficit table is contrasted with
-// the stall counter that results — the same order as multi_simulation.rs:494-508.
+// nudges were summed in log space on the device (Q32 integers) and are applied once per stage — all boosts, clamp, all
+// penalties, clamp (rm::nudge) — which for a batch of ONE episode is the sequential update itself.  Then the batch's best
+// episode competes for the best slot, then the deficit table is contrasted with the stall counter that results — the
+// same order as multi_simulation.rs:494-508.
 int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double cand_metrics[4], const int32_t* cand_n_run,
                                 const uint8_t* cand_run_log, const int32_t* cand_n_def, const uint8_t* cand_def_log,
                                 uint64_t noise_seed) {
@@ -293,14 +297,14 @@ int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double
       for (uint8_t a : p->best_deficit[y]) occ[a] += 1;
       double* row = p->w[y].data();
       for (int a = 0; a < NA; ++a) {
-        const double L = double(n_qual) * double(occ[a]) * ln_boost + (double(pen[y * NA + a]) + double(mild[y * NA + a])) / 4294967296.0;
-        row[a] = rm::nudge(row[a], L);
+        row[a] = rm::nudge(row[a], double(n_qual) * double(occ[a]) * ln_boost, (double(pen[y * NA + a]) + double(mild[y * NA + a])) / 4294967296.0);
       }
     }
     if (p->stall > 1200) for (int y = 0; y < Y; ++y) for (int a = 0; a < NA; ++a) p->w[y][a] = rm::noise(p->w[y][a], noise.next_f64());
   }
   // update_best_strategy with the batch's candidate
   p->iteration_count += uint32_t(n_ok);
+  p->failed_episodes += uint32_t(stats[1]);
   bool improved = false;
   if (cand_metrics && cand_n_run && cand_n_def && n_ok > 0)
     improved = !p->has_best || rm::score(cand_metrics) > rm::score(p->best_metrics.data());
@@ -324,8 +328,7 @@ int32_t eg_policy_apply_reduced(eg_policy* p, const int64_t* stats, const double
         for (uint8_t a : p->best_deficit[y]) { const int s = deficit_slot(a); if (s >= 0) occ[s] += 1; }
         double* row = p->dw[y].data();
         for (int s = 0; s < ND; ++s) {
-          const double L = double(n_ok) * double(occ[s]) * dc.ln_boost + double(dcnt[y * ND + s]) * dc.ln_pen;
-          row[s] = rm::nudge(row[s], L);
+          row[s] = rm::nudge(row[s], double(n_ok) * double(occ[s]) * dc.ln_boost, double(dcnt[y * ND + s]) * dc.ln_pen);
         }
       }
       if (p->stall > 1200) for (int y = 0; y < Y; ++y) for (int s = 0; s < ND; ++s) p->dw[y][s] = rm::noise(p->dw[y][s], noise.next_f64());

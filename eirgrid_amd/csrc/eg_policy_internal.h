@@ -28,6 +28,7 @@ struct eg_policy {
   bool has_best_actions = false, has_best_deficit = false;
   std::array<ActionList, Y> best_actions, best_deficit, cur_run, cur_def;
   uint32_t iteration_count = 0, stall = 0;
+  uint32_t failed_episodes = 0;   // episodes the batch updates saw fail (EG_EP_OVERFLOW, ...): never part of iteration_count
   std::vector<ImprovementRecord> improvement_history;
   void record_improvement(double score, const double m[4]) {   // strategy.rs:71-84
     char buf[32]; std::time_t t = std::time(nullptr); std::tm tmv; localtime_r(&t, &tmv);

@@ -88,11 +88,22 @@ EG_RM DeficitContrast deficit_contrast(double learning_rate, uint32_t stall) {
   return d;
 }
 
-// one entry of the main / deficit table after a batch: w * exp(L), clamped; untouched when L == 0
-EG_RM double nudge(double w, double L) {
-  const double v = clampw(w * exp_nudge(L));
-  return L != 0.0 ? v : w;
+// One entry of the main / deficit table after a batch.  The sequential form (learning.rs:214-252, :339-353) first boosts
+// every occurrence in the best lists (cap MAX_WEIGHT after each factor), then penalises (floor MIN_WEIGHT after each
+// factor); factors >= 1 under a cap and factors <= 1 over a floor commute with their clamp, so the batch form keeps exactly
+// that order with ONE clamp per stage: all boosts (Lb >= 0), clamp, all penalties (Lp <= 0), clamp.  A batch of one
+// episode is then the sequential update itself (to the Q32 rounding of the summed logarithms).  A stage with a zero
+// exponent leaves the entry untouched.
+EG_RM double nudge(double w, double Lb, double Lp) {
+  double v = w;
+  if (Lb != 0.0) v = clampw(v * exp_nudge(Lb));
+  if (Lp != 0.0) v = clampw(v * exp_nudge(Lp));
+  return v;
 }
+// An episode that BEATS the best while contrast is forced (stall > 800) has a negative deterioration: the reference's
+// deterioration.powf(0.3) is NaN, so is every penalty factor derived from it, and (w * NaN).max(MIN_WEIGHT) is MIN_WEIGHT
+// (f64::max returns the other operand).  In log space that is any exponent below ln(MIN/MAX) = -9.2: -20 per occurrence.
+constexpr double kLnNanPenalty = -20.0;
 // stagnation noise of one entry from a uniform draw u in [0, 1) (learning.rs:267-280, :356-369)
 EG_RM double noise(double w, double u) { return clampw(w * (1.0 + 0.25 * (u * 2.0 - 1.0))); }
 

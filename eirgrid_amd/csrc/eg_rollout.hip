@@ -42,6 +42,11 @@ constexpr int kWave = 64;
 constexpr int kD2Max = 144, kD2Stride = 146;   // factor table by squared cell distance: 0..144 (12 km = the largest radius), padded
 constexpr int kCmdYear = 1 << 30;       // helper command: fold next year's starting sums (else: a placement search)
 constexpr int kHelperWaves = 1;         // small-batch kernel: waves per episode beyond the episode wave (see helper_loop)
+// The episode wave polls an LDS flag for the helper's results (s_sleep 1 = 64 cycles per poll).  The helper's longest job —
+// a chunk against 512 generators, or a year's sums over full lists — is a few 10^4 cycles; after 2^20 polls (~30 ms) the
+// protocol must have slipped: the episode ends with EG_EP_INTERNAL instead of hanging the GPU.
+constexpr int kSpinCap = 1 << 20;
+constexpr int kSearchLost = -2;         // place_search: the helper never answered
 constexpr double kMinWeight = 0.0001;   // ai/learning/constants.rs:14
 constexpr double kMaxWeight = 0.999;    // constants.rs:15
 constexpr double kMaxCost = 50000000000.0;   // config/constants.rs:115
@@ -740,6 +745,9 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
         sm.ysum[4] = ys.co2; sm.ysum[5] = ys.tg; sm.ysum[6] = ys.ig; sm.ysum[7] = ys.sg; sm.ysum_opcnt = ys.opcnt;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(EG_TEST_DROP_FLAG) && EG_TEST_DROP_FLAG == 2      // negative build: the sums of 2030 are never announced
+      if (yi == 5) continue;
+#endif
       if (lane == 0) *(volatile uint32_t*)&sm.yflag = sq;
       // ... and the year after that is started over the lists as they are now (they only grow at their ends)
       if (yi + 1 < kYears) {
@@ -769,6 +777,9 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
 #endif
     if (lane == 0) { sm.hres[h - 1].score = b.score; sm.hres[h - 1].m03 = b.m03; sm.hres[h - 1].cell = b.cell; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(EG_TEST_DROP_FLAG) && EG_TEST_DROP_FLAG == 1      // negative build: search results of 2027 are never announced
+    if (yi == 2) continue;
+#endif
     if (lane == 0) *(volatile uint32_t*)&sm.hflag[h - 1] = sq;
   }
 }
@@ -777,8 +788,8 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
 // command): whatever the caller has to do before it needs the result goes there and runs under the records' latency.
 template <int kHelpers, class Between>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
-                                            double* best_m03, PrefixCache& cache0, Between&& between, uint32_t* seq = nullptr,
-                                            unsigned long long* stamps = nullptr) {
+                                            double* best_m03, PrefixCache& cache0, Between&& between, int& nchunks,
+                                            uint32_t* seq = nullptr, unsigned long long* stamps = nullptr) {
   const int info = __builtin_amdgcn_readfirstlane(sm.type_info[type]);      // uniform: list address arithmetic on the scalar unit
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
@@ -789,9 +800,10 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double best = 0.0, m03w = 0.0; int best_c = kCells;
   int first = 0;
-  bool more = true;
+  bool more = true, lost = false;
   // chunk 0 is loaded here, chunk k+1 while chunk k is being evaluated
   PsRec c = list[lane];
+  nchunks += 1 + (kHelpers > 0 ? kHelpers + 1 : 0);      // chunk 0; small-batch kernel: the helpers' chunks and the look-ahead one
   if constexpr (kHelpers > 0) {
     // lanes 0..kHelpers: unpenalised score of the first candidate of chunks 1..kHelpers+1 = the bound of that chunk
     const int bl = (lane <= kHelpers ? lane + 1 : 1) * kWave;
@@ -821,7 +833,12 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 #ifdef EG_STAMPS
       const unsigned long long tw0 = __builtin_readcyclecounter();
 #endif
-      while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[h - 1]) != (int)sq) __builtin_amdgcn_s_sleep(1);
+      // (on a timeout the search carries on with whatever the result slot holds — values are only compared — and reports
+      //  the fault at its end: an early return here cost the episode loop 18 spilled VGPRs)
+      for (int spins = 0; __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.hflag[h - 1]) != (int)sq; ++spins) {
+        __builtin_amdgcn_s_sleep(1);
+        if (spins >= kSpinCap) { lost = true; break; }
+      }
       asm volatile("" ::: "memory");
 #ifdef EG_STAMPS
       if (stamps) { stamps[6] += __builtin_readcyclecounter() - tw0; stamps[27] += sm.hdbg[h - 1][0]; stamps[28] += sm.hdbg[h - 1][1]; stamps[29] += sm.hdbg[h - 1][2]; stamps[30] += 1; }
@@ -846,7 +863,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     const bool below = !(readlane_f64(base, 0) >= best);
     if (chunk > 0 && (kHelpers > 0 ? below : EG_UNI(below))) break;      // sorted descending: lane 0 holds the chunk's bound
     const double te_cur = c.te, cf_cur = c.cf, m03_cur = c.m03; const int cell_cur = (int)c.cell, xy_cur = (int)c.pad;
-    if (chunk + 1 < kChunks) c = list[r + kWave];
+    if (chunk + 1 < kChunks) { c = list[r + kWave]; nchunks += 1; }
 #ifdef EG_STAMPS
     if (stamps) stamps[8] += 1;
     const unsigned long long tg0 = __builtin_readcyclecounter();
@@ -869,6 +886,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   }
   if (best_score) *best_score = best;
   if (best_m03) *best_m03 = m03w;
+  if (lost) return kSearchLost;
   return best > 0.0 ? best_c : -1;
 }
 
@@ -966,6 +984,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   int n_run_y, n_def_y, n_act_y;      // this year's counts
   int status;
   unsigned long long bytes;           // algorithmic bytes of SURVEY §8(d): whole numbers, kept as an integer (scalar registers)
+  int chunks;                         // 64-candidate chunks of sorted candidate records (32 B each) the searches requested
 };
 
 // ---- batch ("reduced") update statistics --------------------------------------------------------------------
@@ -1008,13 +1027,18 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
   if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
-  const bool qualifies = (det > P.threshold || P.forced) && det > 0.0;
+  const bool qualifies = det > P.threshold || P.forced;                                               // learning.rs:160
   unsigned long long q_pen = 0, q_mild = 0;
   if (qualifies) {
     if (lane == 0) atomicAdd(&st[2], 1ull);
-    const double combined = pow(det, 0.3) * P.stagnation;                                            // learning.rs:168-171
-    q_pen = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);    // learning.rs:177
-    q_mild = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);   // learning.rs:247
+    if (det < 0.0) {      // forced contrast on an episode that beats the best: powf(negative, 0.3) is NaN in the reference and
+                          // (w * NaN).max(MIN_WEIGHT) == MIN_WEIGHT — in log space any exponent below -9.2 (eg_reduced_math.h)
+      q_pen = q_mild = (unsigned long long)(long long)(rm::kLnNanPenalty * kQ32);
+    } else {              // det == 0: pow gives 0, both factors are 1 and only the boost remains
+      const double combined = pow(det, 0.3) * P.stagnation;                                            // learning.rs:168-171
+      q_pen = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * 1.5 * combined)) * kQ32);    // learning.rs:177
+      q_mild = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);   // learning.rs:247
+    }
   }
   const uint8_t* run = O.run_log(e);
   const uint8_t* def = O.def_log(e);
@@ -1103,7 +1127,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   EG_MARKG(16);
 
   Episode ep;
-  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0;
   uint8_t* run_log = O.run_log(e);
   uint8_t* def_log = O.def_log(e);
   uint8_t* act_log = O.act_log(e);
@@ -1155,7 +1179,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
       EG_MARKG(18);
       YearSums ys;
       if (sums_from_helper) {      // folded by the helper wave while this wave closed last year
-        while (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.yflag) != (int)year_seq) __builtin_amdgcn_s_sleep(1);
+        // (on a timeout the year carries on with whatever the slots hold until the action loop's own status check ends the
+        //  episode: a separate way out of the year loop from here cost the small-batch kernel 14 spilled VGPRs)
+        for (int spins = 0; __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t*)&sm.yflag) != (int)year_seq; ++spins) {
+          __builtin_amdgcn_s_sleep(1);
+          if (spins >= kSpinCap) { ep.status = EG_EP_INTERNAL; break; }
+        }
         asm volatile("" ::: "memory");
         ys.gcost = sm.ysum[0]; ys.optot = sm.ysum[1]; ys.offs = sm.ysum[2]; ys.ocost = sm.ysum[3];
         ys.co2 = sm.ysum[4]; ys.tg = sm.ysum[5]; ys.ig = sm.ysum[6]; ys.sg = sm.ysum[7]; ys.opcnt = sm.ysum_opcnt;
@@ -1286,14 +1315,14 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         EG_MARKG(20);
 #ifdef EG_STAMPS
         double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, &search_seq, stamps));
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq, stamps));
         stamps[11] += 1;
 #else
         double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, &search_seq));
+        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq));
 #endif
         EG_T1(1);
-        if (cell < 0) { ep.status = EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
+        if (cell < 0) { ep.status = cell == kSearchLost ? EG_EP_INTERNAL : EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         EG_MARKG(21);
         if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) {
@@ -1433,6 +1462,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
     *O.n_offsets(e) = ep.noff;
     *O.n_draws(e) = (unsigned long long)rng.words;
     *O.bytes_moved(e) = (double)ep.bytes;
+    *O.n_chunks(e) = (uint32_t)ep.chunks;
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
@@ -1447,7 +1477,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   }
   if constexpr (kHelpers > 0) {   // release the helper waves
     search_seq += 1;
-    if (lane == 0) sm.cmd[search_seq & 1][0] = -1;
+    if (lane == 0) {
+      sm.cmd[search_seq & 1][0] = -1;
+      // after a protocol fault the helper's sequence number cannot be trusted: it finds the exit command in either buffer
+      // (it has read the command it is working on into registers, so overwriting that buffer is harmless)
+      if (ep.status == EG_EP_INTERNAL) sm.cmd[(search_seq & 1) ^ 1][0] = -1;
+    }
     wg_barrier_lds();
   }
   if (stats != nullptr) {   // fused batch-update statistics: this episode's lists are re-read by all lanes
@@ -1472,7 +1507,8 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   __syncthreads();
   double score = 0.0;
   PrefixCache pc0 = {0.0, -1, 0};
-  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr, pc0, []() {});
+  int nchunks = 0;
+  const int cell = place_search<0>(T, lane, yi, type, n_extra, &score, nullptr, pc0, []() {}, nchunks);
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
@@ -1703,8 +1739,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
       int occ = 0;
       for (int k = s_off[0][y]; k < s_off[0][y + 1]; ++k) occ += s_best[k] == a ? 1 : 0;
       for (int k = s_off[1][y]; k < s_off[1][y + 1]; ++k) occ += s_bestd[k] == a ? 1 : 0;
-      const double L = (double)n_qual * (double)occ * ln_boost + pen_in[k2] / 4294967296.0;
-      double w = rm::nudge(w_in[k2], L);
+      double w = rm::nudge(w_in[k2], (double)n_qual * (double)occ * ln_boost, pen_in[k2] / 4294967296.0);
       if (randomize_main) w = rm::noise(w, draw(i));
       pol[y * snap::kPolRow + a] = w;
     }
@@ -1718,6 +1753,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   if (tid == 0) {
     const bool improved = s_improved != 0;
     st.iteration_count += (uint32_t)n_ok;
+    st.failed_total += (uint32_t)stat(1);
     s_randomized_main = randomize_main ? 1 : 0;
     if (improved) {
       const UpdateCandidate* c = reinterpret_cast<const UpdateCandidate*>(cands + (size_t)s_winner * EG_PACKET_BYTES);
@@ -1778,8 +1814,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
           const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
           occ += slot == sl ? 1 : 0;
         }
-        const double L = (double)n_ok * (double)occ * dc.ln_boost + (double)dcnt_in * dc.ln_pen;
-        double w = rm::nudge(dw_in, L);
+        double w = rm::nudge(dw_in, (double)n_ok * (double)occ * dc.ln_boost, (double)dcnt_in * dc.ln_pen);
         if (randomize) w = rm::noise(w, draw(first_draw + i));
         pol[y * snap::kPolRow + snap::kPolDw + sl] = w;
       }

@@ -71,7 +71,7 @@ class ActionWeights:
     """ActionWeights held by the library (eg_policy): tables, best strategy, counters."""
     SC = dict(learning_rate=0, exploration_rate=1, iterations_without_improvement=2, iteration_count=3, has_best=4,
               best_net_emissions=5, best_opinion=6, best_cost=7, best_reliability=8, has_best_actions=9,
-              has_best_deficit_actions=10, has_count_weights=11, improvement_history_len=12)
+              has_best_deficit_actions=10, has_count_weights=11, improvement_history_len=12, failed_episodes=13)
 
     def __init__(self, handle=None):
         self.h = handle if handle is not None else N.lib().eg_policy_new()
@@ -184,6 +184,7 @@ class BatchResult:
     n_gens: np.ndarray; gen_cell: np.ndarray; gen_pack: np.ndarray
     n_offsets: np.ndarray; off_pack: np.ndarray
     n_draws: np.ndarray; bytes_moved: np.ndarray
+    n_chunks: np.ndarray = None      # [n] chunks of 64 candidate records the searches requested (see include/eirgrid_hip.h)
 
     @staticmethod
     def alloc(n: int) -> "BatchResult":
@@ -192,7 +193,7 @@ class BatchResult:
                            z((n, N.YEARS), np.int32), z((n, N.YEARS), np.int32), z((n, N.RUN_CAP), np.uint8),
                            z((n, N.DEF_CAP), np.uint8), z((n, N.ACT_CAP), np.uint8), z(n, np.int32),
                            z((n, N.MAX_GENS), np.uint16), z((n, N.MAX_GENS), np.uint16), z(n, np.int32),
-                           z((n, N.MAX_OFFSETS), np.uint16), z(n, np.uint64), z(n))
+                           z((n, N.MAX_OFFSETS), np.uint16), z(n, np.uint64), z(n), z(n, np.uint32))
 
     def struct(self) -> N.EgEpisodeOut:
         return N.EgEpisodeOut(_p(self.metrics, C.c_double), _p(self.yearly, C.c_double), _p(self.status, C.c_int32),
@@ -200,15 +201,20 @@ class BatchResult:
                               _p(self.run_log, C.c_uint8), _p(self.def_log, C.c_uint8), _p(self.act_log, C.c_uint8),
                               _p(self.n_gens, C.c_int32), _p(self.gen_cell, C.c_uint16), _p(self.gen_pack, C.c_uint16),
                               _p(self.n_offsets, C.c_int32), _p(self.off_pack, C.c_uint16), _p(self.n_draws, C.c_uint64),
-                              _p(self.bytes_moved, C.c_double))
+                              _p(self.bytes_moved, C.c_double), _p(self.n_chunks, C.c_uint32))
 
     def export_summary_csv(self, path: str, timestamp: str = "", episode: int = 0) -> None:
         """simulation_summary.csv (utils/csv_export.rs:215-432) of one episode of this result."""
         one = BatchResult(*[np.ascontiguousarray(getattr(self, f)[episode:episode + 1]) for f in
                             ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "run_log", "def_log", "act_log", "n_gens",
-                             "gen_cell", "gen_pack", "n_offsets", "off_pack", "n_draws", "bytes_moved")])
+                             "gen_cell", "gen_pack", "n_offsets", "off_pack", "n_draws", "bytes_moved", "n_chunks")])
         out = one.struct()
         N.check(N.lib().eg_export_summary_csv(C.byref(out), path.encode(), timestamp.encode()), "eg_export_summary_csv")
+
+    def bytes_touched(self) -> np.ndarray:
+        """Per episode: the SURVEY §8(d) bytes with the score field of every search (2601 x 8 B, never read by the
+        branch-and-bound search) replaced by the candidate records the search requested (n_chunks x 64 x 32 B)."""
+        return self.bytes_moved - self.n_gens.astype(np.float64) * (N.CELLS * 8.0) + self.n_chunks.astype(np.float64) * (64 * 32.0)
 
     def lists(self, e: int, which: str):
         log = {"run": self.run_log, "def": self.def_log, "act": self.act_log}[which][e]
@@ -326,8 +332,12 @@ class Engine:
     def sync(self):
         N.check(N.lib().eg_sync(self.h), "eg_sync")
 
-    def fetch(self, n_episodes: int) -> BatchResult:
-        res = BatchResult.alloc(n_episodes)
+    def fetch(self, n_episodes: int = None) -> BatchResult:
+        """Every output of the last launched batch (eg_fetch copies eg_last_batch_size() records)."""
+        last = int(N.lib().eg_last_batch_size(self.h))
+        if n_episodes is not None and n_episodes != last:
+            raise ValueError(f"fetch({n_episodes}): the last launched batch holds {last} episodes")
+        res = BatchResult.alloc(last)
         out = res.struct()
         N.check(N.lib().eg_fetch(self.h, C.byref(out)), "eg_fetch")
         return res

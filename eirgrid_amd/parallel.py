@@ -171,6 +171,12 @@ class BatchTrainer:
             return int(self.w.get("improvement_history_len")) - self._history0
         return self._improvements_host
 
+    def failed_episodes(self) -> int:
+        """Episodes (of all ranks) that ended with a status other than EG_EP_OK since the trainer started, as counted by the
+        batch updates (capacity overflows of replay-doubled lists).  Synchronises."""
+        self.sync()
+        return int(self.w.get("failed_episodes"))
+
     def sync(self):
         """Wait for the enqueued steps and bring `weights` up to date (device-resident mode)."""
         if self.device_resident:

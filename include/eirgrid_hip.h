@@ -62,10 +62,12 @@ extern "C" {
 #define EG_ERR_HIP (-3)
 #define EG_ERR_UNSUPPORTED (-4)
 #define EG_ERR_NOMEM (-5)
+#define EG_ERR_INTERNAL (-6)
 
 #define EG_EP_OK 0
 #define EG_EP_OVERFLOW (-1)
 #define EG_EP_NO_LOCATION (-2)
+#define EG_EP_INTERNAL (-3)      /* the kernel's helper-wave protocol timed out (a defect, never an input property): eg_fetch* report EG_ERR_INTERNAL */
 
 /* yearly row columns: the scalar fields of YearlyMetrics, analysis/metrics.rs:7-31 */
 enum {
@@ -132,10 +134,16 @@ typedef struct {
   int32_t *n_offsets;   /* [n] */
   uint16_t *off_pack;   /* [n][EG_MAX_OFFSETS] offset type | year index << 4 | multiplier index << 9 */
   uint64_t *n_draws;    /* [n] words consumed from the episode stream */
-  double *bytes_moved;  /* [n] algorithmic bytes of the episode, SURVEY.md §8(d) formula */
+  double *bytes_moved;  /* [n] algorithmic bytes of the episode, SURVEY.md §8(d) formula (bills the whole 2601 x 8 B score field per search) */
+  uint32_t *n_chunks;   /* [n] 64-candidate chunks of sorted candidate records (32 B each) the episode's searches requested: what the
+                           branch-and-bound search really reads instead of the field; bytes touched = bytes_moved
+                           - n_gens * 2601 * 8 + n_chunks * 64 * 32 */
 } eg_episode_out;
 
 const char *eg_last_error(void);
+/* 16 hex digits: sha256 over the sources this library was built from (csrc/Makefile); eirgrid_amd/_native.py compares it
+ * with the tree it runs in, so that a stale binary next to edited sources is an import error, not a silent mismatch */
+const char *eg_build_hash(void);
 int32_t eg_device_count(void);
 
 eg_ctx *eg_create(int32_t device_ordinal, const eg_world *world);
@@ -155,6 +163,8 @@ int32_t eg_upload_snapshot(eg_ctx *, const eg_policy_snapshot *, const eg_opts *
 int32_t eg_rollout_launch(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes,
                           const uint8_t *replay_mask /* host, may be NULL */);
 int32_t eg_sync(eg_ctx *);
+/* copies the eg_last_batch_size() records of the last launched batch: every non-NULL field of `out` must hold that many */
+uint32_t eg_last_batch_size(const eg_ctx *);
 int32_t eg_fetch(eg_ctx *, eg_episode_out *out);
 /* HIP-event time of the rollout kernel launches since the last call to eg_timing_reset (milliseconds, count). */
 int32_t eg_timing_reset(eg_ctx *);

@@ -22,8 +22,9 @@ LOG_CAP = 4096
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds)."""
     src = os.path.join(_HERE, "eg_oracle.c")
-    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "eg_oracle.h")))
+    deps = [src, os.path.join(_HERE, "eg_oracle.h"), os.path.join(_HERE, "Makefile"),
+            os.path.join(os.path.dirname(_HERE), "include", "eg_detpow.h")]
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "libeg_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH
@@ -99,6 +100,9 @@ def lib():
     L.og_run_episode_tabled.restype = C.c_int32
     L.og_run_episode_tabled.argtypes = [C.POINTER(Tables), C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(EpisodeOut)]
     L.og_post_episode_update.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_uint64]
+    L.og_reduced_batch_update.restype = C.c_int32
+    L.og_reduced_batch_update.argtypes = [C.c_void_p, C.c_int32, i32p, dp, i32p, i32p, u8p, C.c_int32, u8p, C.c_int32,
+                                          C.c_uint64, C.POINTER(C.c_int64), i32p]
     L.og_score_metrics.restype = C.c_double
     L.og_score_metrics.argtypes = [dp, C.c_int32]
     L.og_evaluate_action_impact.restype = C.c_double
@@ -280,6 +284,29 @@ def split_log(log, counts):
 def post_episode_update(shared: OracleWeights, local: OracleWeights, metrics, noise_seed: int = 0):
     m = np.ascontiguousarray(metrics, dtype=np.float64)
     lib().og_post_episode_update(shared.h, local.h, _dp(m), C.c_uint64(noise_seed))
+
+
+STATS_LEN = 8 + 2 * YEARS * NA + YEARS * ND
+
+
+def reduced_batch_update(shared: OracleWeights, status, metrics, n_run, n_def, run_log, def_log, noise_seed: int = 0):
+    """Batch ("reduced") update of SURVEY.md §8(e) / DESIGN.md §2.4 for n episodes that shared the snapshot `shared`
+    (independent libm restatement, oracle/eg_oracle.c og_reduced_batch_update).  Arrays are episode-major: status [n],
+    metrics [n,4], n_run / n_def [n,26], run_log / def_log [n, stride] flat year-major.
+    Returns (improved, stats int64[STATS_LEN], winner index or -1)."""
+    st = np.ascontiguousarray(status, dtype=np.int32); n = st.shape[0]
+    m = np.ascontiguousarray(metrics, dtype=np.float64).reshape(n, 4)
+    nr = np.ascontiguousarray(n_run, dtype=np.int32).reshape(n, YEARS); nd = np.ascontiguousarray(n_def, dtype=np.int32).reshape(n, YEARS)
+    rl = np.ascontiguousarray(run_log, dtype=np.uint8).reshape(n, -1); dl = np.ascontiguousarray(def_log, dtype=np.uint8).reshape(n, -1)
+    ok = st == 0
+    assert (nr[ok].sum(axis=1) <= rl.shape[1]).all() and (nd[ok].sum(axis=1) <= dl.shape[1]).all()
+    stats = np.zeros(STATS_LEN, np.int64); winner = C.c_int32(-1)
+    i32p, u8p = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    improved = lib().og_reduced_batch_update(shared.h, n, st.ctypes.data_as(i32p), _dp(m), nr.ctypes.data_as(i32p), nd.ctypes.data_as(i32p),
+                                             rl.ctypes.data_as(u8p), rl.shape[1], dl.ctypes.data_as(u8p), dl.shape[1],
+                                             C.c_uint64(noise_seed & 0xFFFFFFFFFFFFFFFF), stats.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             C.byref(winner))
+    return bool(improved), stats, winner.value
 
 
 def score_metrics(metrics, cost_only=False):

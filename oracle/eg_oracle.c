@@ -1243,6 +1243,159 @@ void og_post_episode_update(og_weights *shared, const og_weights *local, const d
 }
 
 /* ------------------------------------------------------------------------- */
+/* batch ("reduced") update — SURVEY.md §8(e) reduced mode, DESIGN.md §2.4      */
+/* ------------------------------------------------------------------------- */
+/* INDEPENDENT restatement: written from the definition in DESIGN.md §2.4 / include/eirgrid_hip.h, with libm
+ * log / exp / pow and none of the product's formula headers (csrc/eg_reduced_math.h, include/eg_detpow.h are NOT
+ * used by anything in this section).  It is the checker of k_apply_update / eg_policy_apply_reduced and of the
+ * statistics epilogue of k_rollout.
+ *
+ * Definition.  All n episodes of the batch were sampled from one snapshot P (the state of `s` on entry):
+ *  1. statistics — for every successful episode e: score_e = score_metrics(metrics_e).  If P holds a best strategy
+ *     with both lists: deterioration_e = (best − score_e) / best (0 when best ≤ 0); e QUALIFIES for the contrast step
+ *     when deterioration_e > threshold(stall) or stall > 800 (learning.rs:139-160; an
+ *     episode that beats the best while contrast is forced has a NaN penalty factor in the reference, which its
+ *     f64::max turns into MIN_WEIGHT: ln = -20 here).  A qualifying episode adds, for
+ *     every action occurrence of its year lists (run ++ deficit) that is absent from best ++ best_deficit of that
+ *     year, round(ln(penalty_factor_e)·2^32) to PEN[y][a]; for an occurrence that is present but sits at a position
+ *     j < len(best lists) holding another action, round(ln(mild_penalty_e)·2^32) to MILD[y][a] (learning.rs:168-177,
+ *     :230-251).  Every successful episode (qualifying or not) counts its deficit actions that are absent from
+ *     best_deficit[y] in DCNT[y][slot] (learning.rs:346-352).  Integers: the sums do not depend on the order.
+ *  2. main table (apply_contrast_learning, once): when at least one episode qualified, every entry becomes
+ *     clamp(clamp(w · exp(n_qual·occ(y,a)·ln(boost))) · exp((PEN + MILD)/2^32)) — boosts first, then penalties, as
+ *     the sequential form orders them — with occ = occurrences of a in the best lists of y and boost from the
+ *     snapshot's stall counter (learning.rs:180); a stage with a zero exponent leaves the entry untouched; if
+ *     stall > 1200 every entry then receives the ±25 % noise (learning.rs:267-280) from StdRng(noise_seed), in (y, a) order.
+ *  3. best strategy (update_best_strategy, once): iteration_count += n_ok; the candidate is the successful episode
+ *     with the highest score (ties: lowest index); it replaces the best when there is none or its score is strictly
+ *     greater (stall = 0, best_weights = the table after step 2), else stall += n_ok.
+ *  4. deficit table (apply_deficit_contrast_learning, once, only when step 3 did not improve and P had the lists):
+ *     with the NEW stall counter, entry (y, s) becomes clamp(clamp(dw · exp(n_ok·occ_d(y,s)·ln(boost_d))) · exp(DCNT·ln(penalty_d)));
+ *     noise beyond 1200 continues the same stream.
+ * A batch of ONE episode is the sequential update og_post_episode_update itself, up to the Q32 rounding of the
+ * logarithms (tests/test_reduced_oracle.py); a larger batch differs from n_ok sequential updates in that every episode
+ * is contrasted against the snapshot's best strategy and the clamps are applied once per stage. */
+#define OG_STATS_LEN (8 + 2 * OG_YEARS * OG_NA + OG_YEARS * OG_ND)
+static double reduced_stage(double w, double L) {
+  if (L == 0.0) return w;
+  if (L < -20.0) L = -20.0;   /* a weight lives in [1e-4, 0.999]: beyond e^±9.3 the clamp decides either way */
+  if (L > 20.0) L = 20.0;
+  return clampd(w * exp(L), MIN_WEIGHT, MAX_WEIGHT);
+}
+/* all boosts, clamp, all penalties, clamp: the order of the sequential form (learning.rs:214-252) */
+static double reduced_nudge(double w, double L_boost, double L_penalty) { return reduced_stage(reduced_stage(w, L_boost), L_penalty); }
+int32_t og_reduced_batch_update(og_weights *s, int32_t n, const int32_t *status, const double *metrics /* [n][4] */,
+                                const int32_t *n_run /* [n][26] */, const int32_t *n_def /* [n][26] */,
+                                const uint8_t *run_log, int32_t run_stride, const uint8_t *def_log, int32_t def_stride,
+                                uint64_t noise_seed, int64_t *stats_out /* OG_STATS_LEN or NULL */,
+                                int32_t *winner_out /* index of the candidate or -1; may be NULL */) {
+  int64_t *st = (int64_t *)calloc(OG_STATS_LEN, sizeof(int64_t));
+  int64_t *PEN = st + 8, *MILD = st + 8 + OG_YEARS * OG_NA, *DCNT = st + 8 + 2 * OG_YEARS * OG_NA;
+  const int have_lists = s->has_best && s->has_best_actions && s->has_best_deficit;
+  const double stall = (double)s->stall;
+  const double best_score = s->has_best ? og_score_metrics(s->best_metrics, 0) : 0.0;
+  const double threshold = 0.1 * maxd(exp(-stall / 500.0), 0.00001 / 0.1);
+  const int forced = s->stall > 800;
+  const double stagnation = 1.0 + (0.2 * pow(stall / 10.0, 1.8));
+  const double adaptive_lr = s->learning_rate * (1.0 + 0.1 * stall);
+  int winner = -1; double winner_score = -1.0;
+  for (int e = 0; e < n; ++e) {
+    if (status[e] != 0) { st[1] += 1; continue; }
+    st[0] += 1;
+    const double score = og_score_metrics(metrics + 4 * e, 0);
+    if (score > winner_score) { winner = e; winner_score = score; }
+    if (!have_lists) continue;
+    const double det = best_score > 0.0 ? (best_score - score) / best_score : 0.0;
+    const int qualifies = det > threshold || forced;
+    int64_t q_pen = 0, q_mild = 0;
+    if (qualifies) {
+      st[2] += 1;
+      if (det < 0.0) {   /* powf(negative, 0.3) = NaN, (w * NaN).max(MIN_WEIGHT) = MIN_WEIGHT: an exponent far below ln(MIN/MAX) */
+        q_pen = q_mild = (int64_t)(-20.0 * 4294967296.0);
+      } else {
+        const double combined = pow(det, 0.3) * stagnation;
+        q_pen = (int64_t)llrint(log(1.0 / (1.0 + adaptive_lr * 1.5 * combined)) * 4294967296.0);
+        q_mild = (int64_t)llrint(log(1.0 / (1.0 + adaptive_lr * combined * 0.5)) * 4294967296.0);
+      }
+    }
+    const uint8_t *run = run_log + (size_t)e * (size_t)run_stride, *def = def_log + (size_t)e * (size_t)def_stride;
+    for (int y = 0; y < OG_YEARS; ++y) {
+      const int nr = n_run[e * OG_YEARS + y], nd = n_def[e * OG_YEARS + y];
+      const list_t *b = &s->best_actions[y], *bd = &s->best_deficit[y];
+      for (int j = 0; j < nr + nd; ++j) {
+        const uint8_t a = j < nr ? run[j] : def[j - nr];
+        if (qualifies) {
+          if (!list_contains(b, a) && !list_contains(bd, a)) PEN[y * OG_NA + a] += q_pen;
+          else if (j < b->n + bd->n) {
+            const uint8_t at_j = j < b->n ? b->a[j] : bd->a[j - b->n];
+            if (at_j != a) MILD[y * OG_NA + a] += q_mild;
+          }
+        }
+        if (j >= nr && !list_contains(bd, a)) { const int slot = deficit_index_of(a); if (slot >= 0) DCNT[y * OG_ND + slot] += 1; }
+      }
+      run += nr; def += nd;
+    }
+  }
+  if (winner >= 0) { int64_t bits; memcpy(&bits, &winner_score, 8); st[3] = bits + 1; }
+  if (stats_out) memcpy(stats_out, st, sizeof(int64_t) * OG_STATS_LEN);
+  if (winner_out) *winner_out = winner;
+  const int64_t n_ok = st[0], n_qual = st[2];
+  rng_t noise; rng_seed(&noise, noise_seed);
+  /* 2. main table */
+  if (have_lists && n_qual > 0) {
+    const double ln_boost = log(1.0 + (adaptive_lr * 2.0 * stagnation));
+    for (int y = 0; y < OG_YEARS; ++y)
+      for (int a = 0; a < OG_NA; ++a) {
+        int occ = 0;
+        for (int i = 0; i < s->best_actions[y].n; ++i) occ += s->best_actions[y].a[i] == a;
+        for (int i = 0; i < s->best_deficit[y].n; ++i) occ += s->best_deficit[y].a[i] == a;
+        s->w[y][a] = reduced_nudge(s->w[y][a], (double)n_qual * (double)occ * ln_boost,
+                                   ((double)PEN[y * OG_NA + a] + (double)MILD[y * OG_NA + a]) / 4294967296.0);
+      }
+    if (s->stall > 1200) for (int y = 0; y < OG_YEARS; ++y) randomize_table(s->w[y], OG_NA, &noise);
+  }
+  /* 3. best strategy */
+  s->iteration_count += (uint32_t)n_ok;
+  int improved = 0;
+  if (winner >= 0) improved = !s->has_best || winner_score > og_score_metrics(s->best_metrics, 0);
+  if (improved) {
+    s->has_best = 1; memcpy(s->best_metrics, metrics + 4 * winner, sizeof(s->best_metrics));
+    s->has_best_weights = 1; memcpy(s->best_w, s->w, sizeof(s->best_w));
+    const uint8_t *run = run_log + (size_t)winner * (size_t)run_stride, *def = def_log + (size_t)winner * (size_t)def_stride;
+    for (int y = 0; y < OG_YEARS; ++y) {
+      const int nr = n_run[winner * OG_YEARS + y], nd = n_def[winner * OG_YEARS + y];
+      list_clear(&s->best_actions[y]); for (int i = 0; i < nr; ++i) list_push(&s->best_actions[y], run[i]);
+      list_clear(&s->best_deficit[y]); for (int i = 0; i < nd; ++i) list_push(&s->best_deficit[y], def[i]);
+      list_copy(&s->cur_run[y], &s->best_actions[y]); list_copy(&s->cur_def[y], &s->best_deficit[y]);
+      run += nr; def += nd;
+    }
+    s->has_best_actions = 1; s->has_best_deficit = 1; s->stall = 0;
+  } else s->stall += (uint32_t)n_ok;
+  /* 4. deficit table, with the stall counter step 3 left */
+  if (!improved && have_lists) {
+    const double k = (double)s->stall;
+    const double deterioration = k / 10.0;
+    const double dthreshold = 0.05 * maxd(exp(-k / 400.0), 0.00001 / 0.05);
+    if (deterioration > dthreshold || s->stall > 800) {
+      const double dstag = 1.0 + (0.2 * pow(k / 10.0, 1.8));
+      const double dcombined = pow(deterioration, 0.3) * dstag;
+      const double dlr = s->learning_rate * (1.0 + 0.1 * k);
+      const double ln_pen = log(1.0 / (1.0 + dlr * 1.5 * dcombined));
+      const double ln_boost = log(1.0 + (dlr * 2.0 * dstag * 1.5));
+      for (int y = 0; y < OG_YEARS; ++y)
+        for (int sl = 0; sl < OG_ND; ++sl) {
+          int occ = 0;
+          for (int i = 0; i < s->best_deficit[y].n; ++i) occ += deficit_index_of(s->best_deficit[y].a[i]) == sl;
+          s->dw[y][sl] = reduced_nudge(s->dw[y][sl], (double)n_ok * (double)occ * ln_boost, (double)DCNT[y * OG_ND + sl] * ln_pen);
+        }
+      if (s->stall > 1200) for (int y = 0; y < OG_YEARS; ++y) randomize_table(s->dw[y], OG_ND, &noise);
+    }
+  }
+  free(st);
+  return improved;
+}
+
+/* ------------------------------------------------------------------------- */
 /* KAT helpers                                                                 */
 /* ------------------------------------------------------------------------- */
 void og_world_demand(const og_world *w, int32_t yi, uint32_t *total_pop, double *total_usage) {

@@ -114,6 +114,16 @@ int32_t og_run_episode(const og_world *, og_weights *weights, int32_t replay_bes
 void og_post_episode_update(og_weights *shared, const og_weights *local, const double metrics[4],
                             uint64_t noise_seed);
 
+/* Batch ("reduced") form of the same update for n episodes that shared one snapshot:
+ * independent restatement with libm, the checker of k_apply_update / eg_policy_apply_reduced and of the statistics
+ * epilogue.  Lists are flat year-major per episode (episode e at run_log + e*run_stride).  stats_out (optional):
+ * int64[8 + 2*26*61 + 26*15] in the layout of include/eirgrid_hip.h EG_STATS_LEN.  Returns 1 when the batch's best
+ * episode became the best strategy. */
+int32_t og_reduced_batch_update(og_weights *shared, int32_t n, const int32_t *status, const double *metrics,
+                                const int32_t *n_run, const int32_t *n_def, const uint8_t *run_log, int32_t run_stride,
+                                const uint8_t *def_log, int32_t def_stride, uint64_t noise_seed, int64_t *stats_out,
+                                int32_t *winner_out);
+
 /* ---- "tabled" mode: the same episode evaluated from policy-independent tables (per-year settlement-term table,
  * memoised opinion/cost terms, incrementally maintained aggregates).  The tables are INPUTS here — the tests pass in
  * the ones the product library builds (eg_host_tables_*), which is how they are validated against the literal mode

@@ -364,3 +364,48 @@ def test_capacity_overflow_is_reported_not_hidden(world):
     finally:
         for eng in engines.values():
             eng.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_helper_protocol_timeout_is_an_error_not_a_hang(variant):
+    """The episode wave polls LDS flags for the helper wave's results.  Negative builds (csrc/Makefile `negative`) make
+    the helper withhold a flag — variant 1: the results of every search of 2027, variant 2: the starting sums of 2030.
+    The kernel must finish (bounded polling), every episode that needed the withheld result must end with
+    EG_EP_INTERNAL, eg_fetch must return EG_ERR_INTERNAL, and the process must stay usable."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "eirgrid_amd", f"libeirgrid_hip_neg{variant}.so")
+    assert os.path.exists(lib), f"{lib} missing: make -C eirgrid_amd/csrc negative"
+    code = r"""
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np
+from eirgrid_amd import synthetic_world, _native as N
+from eirgrid_amd.engine import ActionWeights, Engine
+eng = Engine(synthetic_world(), device=0)
+pol = ActionWeights()
+t0 = time.time()
+try:
+    eng.rollout_batch(pol, 12345, 256)
+    print("RESULT no-error")
+except N.EirgridError as e:
+    code = "internal" if "code %%d" %% N.EG_ERR_INTERNAL in str(e) else "other"
+    eng.sync()
+    from eirgrid_amd.engine import BatchResult
+    import ctypes as C
+    st = np.zeros(256, np.int32)
+    out = N.EgEpisodeOut(); out.status = st.ctypes.data_as(C.POINTER(C.c_int32))
+    N.lib().eg_fetch(eng.h, C.byref(out))
+    print("RESULT", code, int((st == N.EG_EP_INTERNAL).sum()), int((st == 0).sum()), "%%.1f" %% (time.time() - t0))
+big = eng.rollout_batch(pol, 12345, 2048)      # the one-wave kernel has no helper: unaffected
+print("BIG", int((big.status == 0).sum()))
+eng.close()
+""" % root
+    env = dict(os.environ, EIRGRID_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    res = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    assert res[1] == "internal", r.stdout
+    n_internal, n_ok, seconds = int(res[2]), int(res[3]), float(res[4])
+    assert n_internal + n_ok == 256 and n_internal >= 50 and seconds < 60
+    assert [l for l in r.stdout.splitlines() if l.startswith("BIG")][0].split()[1] == "2048"
