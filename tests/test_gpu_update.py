@@ -163,7 +163,8 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
-    assert line["config"]["episodes_ok_last_batch"] == 256
+    assert line["config"]["last_batch"]["ok"] == 256 and line["config"]["episodes_failed"] == 0
+    assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["touched_bytes_per_launch"] < line["roofline"]["nominal_bytes_per_launch"]
 
 
 def test_train_step_equals_the_stepwise_path(engine):
