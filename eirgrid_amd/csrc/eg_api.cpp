@@ -69,7 +69,10 @@ struct eg_ctx {
   // timing: a ring of event pairs riding on the rollout dispatches.  A pair is only waited for when the ring comes round to
   // it again (kTimingRing launches later: long finished) or when the caller reads the timing — never inside a training step.
   static constexpr int kTimingRing = 256;
-  hipEvent_t ev0[kTimingRing] = {}, ev1[kTimingRing] = {};
+  hipEvent_t ev[kTimingRing][4] = {};       // start / stop of the heavy grid, start / stop of the lean grid (eg_internal.h RolloutPlan)
+  uint8_t ev_used[kTimingRing] = {};        // bit 0: the heavy pair was recorded, bit 1: the lean pair
+  hipStream_t stream_heavy = nullptr, stream_lean = nullptr;   // the two grids of a split batch run side by side
+  uint32_t* d_index = nullptr; uint32_t index_cap = 0;         // replay / other episode indices of a host-masked batch
   int ring_head = 0, ring_pending = 0;      // next pair to use; pairs recorded and not yet collected (the oldest is head - pending)
   double total_ms = 0.0; int32_t n_launches = 0;
   // eg_place: device buffers kept between calls
@@ -81,6 +84,8 @@ struct eg_ctx {
   uint8_t* d_packet = nullptr; uint8_t* h_packet = nullptr;
   // batches of at most this many episodes run the helper-wave kernel (three waves per episode, all resident at once)
   uint32_t helper_max_episodes = 0;
+  // heavy episodes (eg_rollout.hip place_heavy): pool of penalty fields, one slot per episode that outgrows kHeavyGens
+  uint32_t heavy_slots_wanted = 4096, launch_epoch = 0;
 };
 
 namespace {
@@ -106,25 +111,92 @@ int ensure_outputs(eg_ctx* c, uint32_t n) {
   return EG_OK;
 }
 
-// collects the oldest `count` recorded pairs (all of them when count < 0)
+// collects the oldest `count` recorded launches (all of them when count < 0).  A batch that ran as two grids counts as
+// ONE launch lasting from the earlier start to the later end.
 int collect_timing(eg_ctx* c, int count = -1) {
   if (count < 0 || count > c->ring_pending) count = c->ring_pending;
   for (; count > 0; --count) {
     const int i = (c->ring_head - c->ring_pending + 2 * eg_ctx::kTimingRing) % eg_ctx::kTimingRing;
-    EG_HIP(hipEventSynchronize(c->ev1[i]));
-    float ms = 0.f;
-    EG_HIP(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
-    c->total_ms += double(ms); c->n_launches += 1; c->ring_pending -= 1;
+    const bool heavy = c->ev_used[i] & 1, lean = c->ev_used[i] & 2;
+    float best = 0.f;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        if (!(a ? lean : heavy) || !(b ? lean : heavy)) continue;
+        EG_HIP(hipEventSynchronize(c->ev[i][2 * b + 1]));
+        float ms = 0.f;
+        EG_HIP(hipEventElapsedTime(&ms, c->ev[i][2 * a], c->ev[i][2 * b + 1]));
+        if (ms > best) best = ms;
+      }
+    c->total_ms += double(best); c->n_launches += 1; c->ring_pending -= 1;
   }
   return EG_OK;
 }
-// the event pair of the next rollout launch (frees the oldest one first when the ring is full)
-int next_timing_slot(eg_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
-  if (c->ring_pending == eg_ctx::kTimingRing) { int rc = collect_timing(c, 1); if (rc != EG_OK) return rc; }
-  *e0 = c->ev0[c->ring_head]; *e1 = c->ev1[c->ring_head];
+// before every rollout launch: the field pool exists (allocated on first use) and the launch has an epoch of its own
+int prepare_heavy(eg_ctx* c) {
+  constexpr size_t kSlotBytes = size_t(kRadiusClasses) * 2624 * sizeof(double);
+  if (!c->dev.heavy && c->heavy_slots_wanted > 0) {
+    void* pool = nullptr; void* claim = nullptr;
+    if (hipMalloc(&pool, kSlotBytes * c->heavy_slots_wanted) != hipSuccess || hipMalloc(&claim, 64) != hipSuccess) {
+      (void)hipGetLastError();
+      if (pool) (void)hipFree(pool);
+      c->heavy_slots_wanted = 0;      // no memory for it: heavy episodes take the exact scan
+    } else {
+      EG_HIP(hipMemset(claim, 0xFF, 64));      // an epoch no launch uses
+      c->allocs.push_back(pool); c->allocs.push_back(claim);
+      c->dev.heavy = static_cast<uint8_t*>(pool); c->dev.heavy_claim = static_cast<unsigned*>(claim); c->dev.heavy_slots = c->heavy_slots_wanted;
+    }
+  }
+  c->launch_epoch = (c->launch_epoch + 1u) & 0xFFFu;
+  if (c->launch_epoch == 0xFFFu) c->launch_epoch = 0u;      // 0xFFF is the "never" epoch the claim word starts with
+  c->dev.heavy_epoch = c->launch_epoch;
   return EG_OK;
 }
-void timing_launched(eg_ctx* c) { c->ring_head = (c->ring_head + 1) % eg_ctx::kTimingRing; c->ring_pending += 1; }
+// One batch = up to two grids of k_rollout (eg_internal.h RolloutPlan): the episodes that replay the best strategy on the
+// heavy-capable variant, the others on the lean one, on two streams side by side.  `host_mask` (n bytes, may be NULL):
+// which episodes replay; otherwise `period` (0: none): episode i replays when (first_index + i) % period == 0.
+// Uploads the mask and the index lists, takes a slot of the timing ring, gives the launch its field-pool epoch, launches.
+int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, const uint8_t* host_mask, uint32_t period, long long* d_stats) {
+  if (n == 0) return EG_OK;
+  RolloutPlan plan{};
+  plan.helper_waves = n <= c->helper_max_episodes;
+  plan.n_lean = n;
+  const uint8_t* d_mask = nullptr;
+  if (host_mask) {
+    if (n > c->mask_cap) { if (c->d_mask) (void)hipFree(c->d_mask); c->d_mask = nullptr; EG_HIP(hipMalloc((void**)&c->d_mask, n)); c->mask_cap = n; }
+    if (n > c->index_cap) { if (c->d_index) (void)hipFree(c->d_index); c->d_index = nullptr; EG_HIP(hipMalloc((void**)&c->d_index, sizeof(uint32_t) * n)); c->index_cap = n; }
+    std::vector<uint32_t> idx(n);
+    uint32_t nh = 0;
+    for (uint32_t i = 0; i < n; ++i) if (host_mask[i]) idx[nh++] = i;
+    uint32_t k = nh;
+    for (uint32_t i = 0; i < n; ++i) if (!host_mask[i]) idx[k++] = i;
+    EG_HIP(hipMemcpy(c->d_mask, host_mask, n, hipMemcpyHostToDevice));
+    EG_HIP(hipMemcpy(c->d_index, idx.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    d_mask = c->d_mask;
+    plan.n_heavy = nh; plan.n_lean = n - nh; plan.mode = 1u; plan.d_index = c->d_index;
+  } else if (period == 1u) {
+    plan.n_heavy = n; plan.n_lean = 0;
+  } else if (period > 1u) {
+    plan.off = uint32_t((uint64_t(period) - first_index % period) % period);
+    plan.n_heavy = plan.off < n ? (n - plan.off + period - 1u) / period : 0u;
+    plan.n_lean = n - plan.n_heavy; plan.mode = 2u; plan.period = period;
+  }
+  if (c->ring_pending == eg_ctx::kTimingRing) { int rc = collect_timing(c, 1); if (rc != EG_OK) return rc; }
+  const int slot = c->ring_head;
+  for (int k = 0; k < 4; ++k) plan.ev[k] = c->ev[slot][k];
+  // a batch that is one grid stays on the null stream like every other kernel of the library; two grids go to two streams
+  // of their own (blocking streams: they wait for earlier null-stream work, later null-stream work waits for them)
+  const bool split = plan.n_heavy > 0 && plan.n_lean > 0;
+  plan.stream_heavy = split ? c->stream_heavy : nullptr;
+  plan.stream_lean = split ? c->stream_lean : nullptr;
+  int rc = prepare_heavy(c);
+  if (rc != EG_OK) return rc;
+  const int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, period, d_stats, plan);
+  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  c->ev_used[slot] = uint8_t((plan.n_heavy > 0 ? 1 : 0) | (plan.n_lean > 0 ? 2 : 0));
+  c->ring_head = (c->ring_head + 1) % eg_ctx::kTimingRing; c->ring_pending += 1;
+  c->last_n = n; c->last_first = first_index;
+  return EG_OK;
+}
 
 }  // namespace
 
@@ -151,6 +223,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess) cus = 0;
     c->helper_max_episodes = 4u * (uint32_t)(cus > 0 ? cus : 0);
+    // EIRGRID_HEAVY_SLOTS: field slots for heavy episodes (default 4096 = 516 MB; 0 = every search is the exact scan)
+    if (const char* hs = std::getenv("EIRGRID_HEAVY_SLOTS")) c->heavy_slots_wanted = (uint32_t)std::strtoul(hs, nullptr, 10);
+    if (c->heavy_slots_wanted > (1u << 20) - 1u) c->heavy_slots_wanted = (1u << 20) - 1u;
     if (const char* hv = std::getenv("EIRGRID_HELPER_WAVES")) {
       if (std::string(hv) == "0") c->helper_max_episodes = 0;
       else if (std::string(hv) == "all") c->helper_max_episodes = 0xFFFFFFFFu;
@@ -216,7 +291,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   }
   D.size_factor = H.size_factor; D.n_existing = world->n_existing;
   for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
-    if (hipEventCreate(&c->ev0[i]) != hipSuccess || hipEventCreate(&c->ev1[i]) != hipSuccess) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; }
+    for (int k = 0; k < 4; ++k)
+      if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; break; }
+  if (rc == EG_OK && (hipStreamCreate(&c->stream_heavy) != hipSuccess || hipStreamCreate(&c->stream_lean) != hipSuccess)) { set_error("hipStreamCreate failed"); rc = EG_ERR_HIP; }
   if (rc == EG_OK) {
     if (hipMalloc((void**)&c->d_snap, snap::total) != hipSuccess || hipHostMalloc((void**)&c->h_snap, snap::total) != hipSuccess) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
@@ -237,10 +314,11 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_packet) (void)hipFree(c->d_packet);
   if (c->h_packet) (void)hipHostFree(c->h_packet);
   free_outputs(c);
-  for (int i = 0; i < eg_ctx::kTimingRing; ++i) {
-    if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
-    if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
-  }
+  for (int i = 0; i < eg_ctx::kTimingRing; ++i)
+    for (int k = 0; k < 4; ++k) if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
+  if (c->stream_heavy) (void)hipStreamDestroy(c->stream_heavy);
+  if (c->stream_lean) (void)hipStreamDestroy(c->stream_lean);
+  if (c->d_index) (void)hipFree(c->d_index);
   if (c->d_place_cells) (void)hipFree(c->d_place_cells);
   if (c->d_place_cell) (void)hipFree(c->d_place_cell);
   if (c->d_place_score) (void)hipFree(c->d_place_score);
@@ -338,20 +416,7 @@ int32_t eg_rollout_launch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32
   EG_HIP(hipSetDevice(c->device));
   int rc = ensure_outputs(c, n);
   if (rc != EG_OK) return rc;
-  const uint8_t* d_mask = nullptr;
-  if (replay_mask) {
-    if (n > c->mask_cap) { if (c->d_mask) (void)hipFree(c->d_mask); c->d_mask = nullptr; EG_HIP(hipMalloc((void**)&c->d_mask, n)); c->mask_cap = n; }
-    EG_HIP(hipMemcpy(c->d_mask, replay_mask, n, hipMemcpyHostToDevice));
-    d_mask = c->d_mask;
-  }
-  hipEvent_t e0, e1;
-  rc = next_timing_slot(c, &e0, &e1);
-  if (rc != EG_OK) return rc;
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, nullptr, nullptr, n <= c->helper_max_episodes, e0, e1);
-  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  timing_launched(c);
-  c->last_n = n; c->last_first = first_index;
-  return EG_OK;
+  return launch_batch(c, seed, first_index, n, replay_mask, 0u, nullptr);
 }
 
 int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, const uint8_t* replay_mask, void* d_packet) {
@@ -359,21 +424,11 @@ int32_t eg_rollout_launch_update(eg_ctx* c, uint64_t seed, uint64_t first_index,
   EG_HIP(hipSetDevice(c->device));
   int rc = ensure_outputs(c, n ? n : 1);
   if (rc != EG_OK) return rc;
-  const uint8_t* d_mask = nullptr;
-  if (replay_mask && n) {
-    if (n > c->mask_cap) { if (c->d_mask) (void)hipFree(c->d_mask); c->d_mask = nullptr; EG_HIP(hipMalloc((void**)&c->d_mask, n)); c->mask_cap = n; }
-    EG_HIP(hipMemcpyAsync(c->d_mask, replay_mask, n, hipMemcpyHostToDevice, nullptr));
-    d_mask = c->d_mask;
-  }
-  hipEvent_t e0, e1;
-  rc = next_timing_slot(c, &e0, &e1);
-  if (rc != EG_OK) return rc;
   EG_HIP(hipMemsetAsync(d_packet, 0, EG_PACKET_BYTES, nullptr));
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, 0u, (long long*)d_packet, nullptr, n <= c->helper_max_episodes, e0, e1);
-  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  if (n > 0) timing_launched(c);      // (launch_rollout does not launch an empty batch)
   c->last_n = n; c->last_first = first_index;
-  lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
+  rc = launch_batch(c, seed, first_index, n, replay_mask, 0u, (long long*)d_packet);
+  if (rc != EG_OK) return rc;
+  int lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
@@ -544,16 +599,10 @@ int device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, u
   EG_HIP(hipSetDevice(c->device));
   int rc = ensure_outputs(c, n);
   if (rc != EG_OK) return rc;
-  hipEvent_t e0, e1;
-  rc = next_timing_slot(c, &e0, &e1);
+  rc = launch_batch(c, seed, first_index, n, nullptr, replay_period, (long long*)d_packet);
   if (rc != EG_OK) return rc;
-  int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, nullptr, replay_period, (long long*)d_packet, nullptr,
-                          n <= c->helper_max_episodes, e0, e1);
-  if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  timing_launched(c);
-  c->last_n = n; c->last_first = first_index;
   if (!pick) return EG_OK;
-  lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
+  int lr = launch_pick_best(c->out, n, first_index, reinterpret_cast<UpdateCandidate*>(static_cast<uint8_t*>(d_packet) + 8 * EG_STATS_LEN), nullptr);
   if (lr != 0) { set_error(std::string("k_pick_best launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }

@@ -101,6 +101,11 @@ struct DevTables {
   const uint8_t* base;
   double size_factor;
   int32_t n_existing;
+  // heavy episodes (eg_rollout.hip, place_heavy): a pool of per-episode penalty fields [6][2624] f64 in HBM, claimed per
+  // launch through `heavy_claim` (launch epoch << 20 | slots handed out)
+  uint32_t heavy_slots, heavy_epoch;
+  uint8_t* heavy;
+  unsigned* heavy_claim;
 #define EG_TAB(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + tab::name); }
   EG_TAB(usage, double) EG_TAB(population, double)
   EG_TAB(pre_co2, double) EG_TAB(pre_tg, double) EG_TAB(pre_ig, double) EG_TAB(pre_sg, double) EG_TAB(pre_optot, double)
@@ -230,9 +235,20 @@ double action_cost_estimate(int action, int year_index);      // eg_tables.cpp; 
 // launchers implemented in eg_rollout.hip
 struct StatsParams;
 struct UpdateCandidate;
+// How a batch is split over the two variants of k_rollout (eg_rollout.hip, EpisodeMap): n_heavy episodes — the ones that
+// replay the best strategy — on the heavy-capable variant, n_lean on the lean one, on two streams side by side when both
+// are present.  mode 1: d_index holds the n_heavy replay episodes followed by the n_lean others; mode 2: the replays are
+// off + period * j.  ev: start / stop events of the heavy and of the lean grid (only the ones launched are recorded).
+struct RolloutPlan {
+  bool helper_waves;
+  void* stream_heavy; void* stream_lean;
+  uint32_t n_heavy, n_lean, mode;
+  const uint32_t* d_index;
+  uint32_t off, period;
+  void* ev[4];
+};
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
-                   bool helper_waves, void* ev_start, void* ev_stop);
+                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& plan);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
 int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
 // `o`, n_local, first_index: the batch the own packet came from (the winner's record is kept when it is one of them)

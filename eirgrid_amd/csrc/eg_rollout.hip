@@ -890,6 +890,227 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   return best > 0.0 ? best_c : -1;
 }
 
+
+// ---- heavy episodes: placement against a long generator list --------------------------------------------------------
+// The branch-and-bound scan above evaluates whole chunks exactly, O(generators) per chunk.  That is the right trade for
+// the 25-45 generators of a sampled episode (2-5 chunks per search), but a replay episode places hundreds (the
+// reference's replay records and applies every action twice, SURVEY Q15: 228-468 generators once a replay episode has
+// become the best strategy): the best-scoring cells are all taken, the scan goes 15-41 chunks deep, and such an episode
+// took 40x the time of a sampled one — a launch lasts as long as its slowest episode.
+// From kHeavyGens generators on, an episode keeps in global memory, per radius class, the product of the penalty factors
+// of all its generators for every cell: field[rc][cell] (year-independent; folded in any order, it only serves a bound).
+// A search then is
+//   1. approx(c) = ((te * cf) * size) * field[rc][c] over the sorted candidates — one gather and three multiplications
+//      per candidate instead of a pass over the generator list — with the same stop rule as the exact scan
+//      (field <= 1, so approx(c) <= base(c));
+//   2. every candidate with approx >= M * (1 - 2^-30), M the largest approx, is evaluated EXACTLY: the reference's
+//      product in list order (chunk_product), first maximum in cell order (chunk_reduce).
+// Exactness: exact(c) and approx(c) are both the real product te * cf * size * prod f rounded at most G + 3 times each,
+// so they differ by less than 2 (G + 3) 2^-53 < 2^-42 relative while no intermediate is subnormal; the arg-max of the
+// exact scores (and every cell tied with it) therefore lies within 2^-41 of M and is among the candidates, and a cell
+// below the threshold cannot reach the exact score of M's holder.  Subnormal ranges (M < 1e-250), more than 64
+// candidates, or no free field slot fall back to the exact scan above.  Results are the exact scan's, bit for bit.
+constexpr int kHeavyGens = 64;
+constexpr int kFieldStride = 2624;                   // doubles per radius class of a field slot
+constexpr int kSearchFallback = -3;
+// The three functions below are not inlined (they would cost the episode loop its registers), and a pointer that crosses a
+// call loses its address space: they take ADDRESSES and make global-memory pointers of them, so that the loads stay
+// global_load / global_store instead of flat ones.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1)))* GlobalVec4;
+typedef double __attribute__((address_space(1)))* GlobalF64;
+__device__ __forceinline__ PsRec load_rec(unsigned long long list_addr, int i) {
+  const GlobalVec4 p = (GlobalVec4)(list_addr + (unsigned long long)(unsigned)i * sizeof(PsRec));
+  const u32x4 lo = p[0], hi = p[1];
+  PsRec r;
+  __builtin_memcpy(&r, &lo, 16); __builtin_memcpy(reinterpret_cast<char*>(&r) + 16, &hi, 16);
+  return r;
+}
+__device__ __forceinline__ double field_load(GlobalF64 p) {      // past the CU's L1: the wave wrote this entry itself
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kLatency>
+__device__ __forceinline__ double factor_by_q(int rc, int q) {
+  if constexpr (kLatency) return sl.dr16[2 * (rc * kD2Stride + q)];
+  else return sm.dr[rc * kD2Stride + q];
+}
+// one slot of the pool for this launch, or -2 (pool exhausted / absent).  The claim word holds launch epoch << 20 | count,
+// so no launch has to reset it.
+__device__ __forceinline__ int heavy_claim(const DevTables& T, int lane) {
+  int slot = -2;
+  if (lane == 0 && T.heavy != nullptr) {
+    unsigned* w = T.heavy_claim;
+    const unsigned epoch = T.heavy_epoch & 0xFFFu;
+    unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int guard = 0; guard < 1000000; ++guard) {
+      unsigned desired, mine;
+      if ((old >> 20) != epoch) { desired = (epoch << 20) | 1u; mine = 0u; }
+      else { mine = old & 0xFFFFFu; if (mine >= T.heavy_slots) break; desired = old + 1u; }
+      const unsigned prev = atomicCAS(w, old, desired);
+      if (prev == old) { slot = (int)mine; break; }
+      old = prev;
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(slot);
+}
+// field[rc][c] *= d/R of a generator at `cell`, for every class and every cell within reach (`reaches`: 4 bits per class).
+// The whole update is ONE memory round trip: every lane first requests all the entries it will touch (kFieldOps[rc]
+// blocks of 64 cells cover the (2 reach + 1)^2 box of class rc: reach 11, 7, 4, 6, 5, 2 cells for the reference's radii of
+// 12, 8, 5, 7, 6, 3 km in the class order of eg_tables.cpp — heavy_ops_fit checks that), then multiplies and stores.
+// Entries are distinct, so the order is free.
+constexpr int kFieldOps[kRadiusClasses] = {9, 4, 2, 3, 2, 1};
+constexpr int kFieldOpsTotal = 21;
+__device__ __forceinline__ bool heavy_ops_fit(int reaches) {
+  bool ok = true;
+  for (int rc = 0; rc < kRadiusClasses; ++rc) { const int w = 2 * ((reaches >> (4 * rc)) & 15) + 1; ok = ok && (w * w <= kWave * kFieldOps[rc]); }
+  return ok;
+}
+template <bool kLatency>
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int reaches, int lane, int cell) {
+#ifdef EG_STAMPS
+  const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+  const int gi = cell / kGrid, gj = cell - gi * kGrid;
+  double val[kFieldOpsTotal], fac[kFieldOpsTotal]; int off[kFieldOpsTotal];
+  int slot = 0;
+#pragma unroll
+  for (int rc = 0; rc < kRadiusClasses; ++rc) {
+    const int reach = (reaches >> (4 * rc)) & 15;
+    const int w = 2 * reach + 1, n = w * w;
+    const float inv_w = 1.0f / (float)w;
+    const GlobalF64 f = (GlobalF64)(field_addr + (unsigned long long)(rc * kFieldStride) * 8ull);
+#pragma unroll
+    for (int k = 0; k < kFieldOps[rc]; ++k, ++slot) {
+      const int idx = lane + kWave * k;
+      const int row = (int)(((float)idx + 0.5f) * inv_w);      // idx / w, exact for idx < 625, w <= 25
+      const int di = row - reach, dj = idx - row * w - reach;
+      const int ci = gi + di, cj = gj + dj;
+      off[slot] = -1; fac[slot] = 1.0; val[slot] = 1.0;
+      if (idx < n && ci >= 0 && ci < kGrid && cj >= 0 && cj < kGrid) {
+        int q = di * di + dj * dj; q = q < kD2Max ? q : kD2Max;
+        fac[slot] = factor_by_q<kLatency>(rc, q);
+        if (fac[slot] != 1.0) { off[slot] = rc * kFieldStride + ci * kGrid + cj; val[slot] = field_load(f + (ci * kGrid + cj)); }
+      }
+    }
+  }
+  const GlobalF64 base = (GlobalF64)field_addr;
+#pragma unroll
+  for (int k = 0; k < kFieldOpsTotal; ++k)
+    if (off[k] >= 0) base[off[k]] = val[k] * fac[k];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are in L2 before anything gathers from the field
+#ifdef EG_STAMPS
+  if (lane == 0) sm.hdbg[0][3] += __builtin_readcyclecounter() - ts0;
+#endif
+}
+// the episode turns heavy: all ones, then every generator placed so far
+template <bool kLatency>
+__device__ __noinline__ void heavy_enter(unsigned long long field_addr, int reaches, int lane, int ngen) {
+  const GlobalF64 f = (GlobalF64)field_addr;
+  for (int i = lane; i < kRadiusClasses * kFieldStride; i += kWave) f[i] = 1.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int g = 0; g < ngen; ++g) heavy_add<kLatency>(field_addr, reaches, lane, (int)(sm.gcell[g] & 0xFFF));
+}
+// `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
+// returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
+template <bool kLatency>
+__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, double size_factor, int lane, int rc, int ngen) {
+#ifdef EG_STAMPS
+  const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+  const GlobalF64 A = (GlobalF64)class_addr;
+  const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
+  constexpr int kChunks = (kCells + kWave - 1) / kWave;      // 41: the list holds exactly kChunks * 64 records
+  constexpr int kGroup = 4, kGroups = (kChunks + kGroup - 1) / kGroup;
+  constexpr double kKeep = 1.0 - 0x1p-30;
+  // 1. largest approximate score M, scanning in descending order of the unpenalised score, four chunks per memory round
+  //    trip (the records of the next group are requested while this group's field entries are on their way).  A lane
+  //    remembers up to two of its entries that were within 2^-30 of the running maximum when it saw them — M only grows,
+  //    so whatever is within 2^-30 of the final M was so then.  A third one (ties en masse) sends the search to pass 2.
+  double M = 0.0; int K = 0;
+  double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
+  PsRec c[kGroup], nx[kGroup];
+#pragma unroll
+  for (int j = 0; j < kGroup; ++j) c[j] = load_rec(list_addr, j * kWave + lane);
+  for (int g = 0; g < kGroups; ++g) {
+    double base[kGroup], ap[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) base[j] = (c[j].te * c[j].cf) * size_factor;
+    if (g > 0 && !(readlane_f64(base[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) ap[j] = field_load(A + c[j].cell);
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) {
+      const int ch = (g + 1) * kGroup + j;
+      nx[j].te = 0.0; nx[j].cf = 1.0; nx[j].m03 = 0.0; nx[j].cell = 0u; nx[j].pad = 0u;
+      if (ch < kChunks) nx[j] = load_rec(list_addr, ch * kWave + lane);
+    }
+    double local = 0.0;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) { ap[j] = base[j] * ap[j]; local = dmax(local, ap[j]); }
+    M = dmax(M, wave_max_f64(local));
+    const double thr_now = M * kKeep;
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j)
+      if (ap[j] >= thr_now && ap[j] > 0.0) {
+        const int rank = (g * kGroup + j) * kWave + lane;
+        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; }
+        else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
+        else over = true;
+      }
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) c[j] = nx[j];
+    K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
+  }
+  if (!(M >= 1e-250)) return kSearchFallback;      // (nothing placeable, or subnormal territory: the exact scan decides)
+#ifdef EG_STAMPS
+  const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+  // 2. the candidates: everything within 2^-30 of M
+  const double thr = M * kKeep;
+  int ncand = 0;
+  if (__ballot(over) == 0ull) {
+    const unsigned long long m1 = __ballot(q1r >= 0 && q1v >= thr), m2 = __ballot(q2r >= 0 && q2v >= thr);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n1 = __popcll(m1);
+    if ((m1 >> lane) & 1ull) sm.gstage[1][__popcll(m1 & below)] = q1r;
+    const int p2 = n1 + __popcll(m2 & below);
+    if (((m2 >> lane) & 1ull) && p2 < kWave) sm.gstage[1][p2] = q2r;
+    ncand = n1 + __popcll(m2);
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const PsRec r = load_rec(list_addr, k * kWave + lane);
+      const double approx = ((r.te * r.cf) * size_factor) * field_load(A + r.cell);
+      const unsigned long long m = __ballot(approx >= thr && approx > 0.0);
+      if (m != 0ull) {
+        const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+        if (((m >> lane) & 1ull) && pos < kWave) sm.gstage[1][pos] = k * kWave + lane;
+        ncand += __popcll(m);
+      }
+    }
+  }
+  if (ncand > kWave || ncand == 0) return kSearchFallback;
+  wave_sync();
+  // 3. exact scores of the candidates: the reference's product in list order, first maximum in cell order
+  const int r = lane < ncand ? sm.gstage[1][lane] : kCells;
+  PsRec e; e.te = 0.0; e.cf = 1.0; e.m03 = 0.0; e.cell = 0u; e.pad = 0u;
+  if (r < kCells) e = load_rec(list_addr, r);
+#ifdef EG_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+  const int table = kLatency ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
+  const double s = chunk_score<kLatency>(table, size_factor, lane, ngen_s, r, e.te, e.cf, (int)e.cell, (int)e.pad);
+  const ChunkBest b = chunk_reduce<false>(s, (int)e.cell, e.m03);
+  if (!(b.score > 0.0)) return kSearchFallback;
+#ifdef EG_STAMPS
+  if (lane == 0) { sm.hdbg[0][0] += ts1 - ts0; sm.hdbg[0][1] += ts2 - ts1; sm.hdbg[0][2] += __builtin_readcyclecounter() - ts2; sm.hdbg[1][0] += (unsigned long long)K; sm.hdbg[1][1] += (unsigned long long)ncand; sm.hdbg[1][2] += 1ull; }
+#endif
+  wave_sync();
+  if (lane == 0) sm.hres[1].m03 = b.m03;
+  wave_sync();
+  return b.cell | ((K + 1) << 16);      // (a second pass re-reads the first pass's records)
+}
+
 // ---- weight nudges -----------------------------------------------------------------------------------------
 // update_deficit_weights(action, d_improvement) followed by update_weights(action, w_improvement), as the repair loop calls
 // them after every applied action (simulation.rs:453-486).  Every table entry receives at most one factor from each
@@ -985,6 +1206,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   int status;
   unsigned long long bytes;           // algorithmic bytes of SURVEY §8(d): whole numbers, kept as an integer (scalar registers)
   int chunks;                         // 64-candidate chunks of sorted candidate records (32 B each) the searches requested
+  int heavy;                          // field slot of a heavy episode (place_heavy); -1: not asked for yet, -2: none to be had
 };
 
 // ---- batch ("reduced") update statistics --------------------------------------------------------------------
@@ -1081,15 +1303,36 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 #define EG_TE(slot) do {} while (0)
 #endif
 
-template <int kHelpers>
+// Which episode of the batch a workgroup runs.  A batch is launched as up to two grids that run side by side on two
+// streams: the episodes that replay the best strategy — the ones that grow long generator lists, SURVEY Q15 — on the
+// kHeavy variant of the kernel (approximate-field placement from kHeavyGens generators on), all others on the lean
+// variant, whose code and registers are those of a kernel without the heavy path (measured: with the heavy calls compiled
+// into the one kernel, sampled episodes ran 8 % / 13 % slower at 1 024 / 16 384 episodes).
+struct EpisodeMap {
+  const uint32_t* index;      // mode 1: episode = index[workgroup]
+  uint32_t mode;              // 0: the workgroup index; 2: off + period * workgroup (the replays of a period); 3: the others
+  uint32_t count, off, period;
+};
+__device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b) {
+  if (m.mode == 0u) return b;
+  if (m.mode == 1u) return m.index[b];
+  if (m.mode == 2u) return m.off + m.period * b;
+  if (b < m.off) return b;
+  const uint32_t q = b - m.off, p1 = m.period - 1u;
+  return m.off + (q / p1) * m.period + 1u + q % p1;
+}
+
+template <int kHelpers, bool kHeavy>
 __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
                                                                     const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
-                                                                    long long* stats) {
+                                                                    long long* stats, EpisodeMap emap) {
   const int lane = threadIdx.x & (kWave - 1);
-  const uint32_t e = blockIdx.x;
+  if (blockIdx.x >= emap.count) return;
+  const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
   uint32_t search_seq = 0, year_seq = 0;      // commands to the helper wave share one sequence
+  int heavy_reaches = 0;                      // heavy episodes: reach of the six radius classes, four bits each
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1117,6 +1360,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   unsigned long long last_ = t_begin;
 #endif
 
+#ifdef EG_STAMPS
+  if (kHeavy && lane < 8) sm.hdbg[lane >> 2][lane & 3] = 0ull;
+#endif
   load_static_tables(T, lane, kHelpers == 0);
   // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
   const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
@@ -1127,7 +1373,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   EG_MARKG(16);
 
   Episode ep;
-  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0; ep.heavy = -1;
   uint8_t* run_log = O.run_log(e);
   uint8_t* def_log = O.def_log(e);
   uint8_t* act_log = O.act_log(e);
@@ -1313,14 +1559,38 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
           t12v = T.t12()[(unsigned)yi * kTypes + t];
         };
         EG_MARKG(20);
+        double m03v = 0.0;
+        int cell = -1;
+        bool placed = false;
+        if constexpr (kHeavy) if (ep.ngen >= kHeavyGens && ep.heavy != -2) {      // a long list: approximate field + exact evaluation of the few candidates
+          const unsigned long long slot_bytes = (unsigned long long)(kRadiusClasses * kFieldStride) * 8ull;
+          if (ep.heavy == -1) {
+            ep.heavy = heavy_claim(T, lane);
+            if (ep.heavy >= 0) {
+              heavy_reaches = 0;
+              for (int k = 0; k < kRadiusClasses; ++k) heavy_reaches |= (T.reach()[k] & 15) << (4 * k);
+              heavy_reaches = __builtin_amdgcn_readfirstlane(heavy_reaches);
+              if (!heavy_ops_fit(heavy_reaches)) ep.heavy = -2;      // other radii than the reference's: exact scans only
+              else heavy_enter<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes, heavy_reaches, lane, ep.ngen);
+            }
+          }
+          if (ep.heavy >= 0) {
+            const int info = __builtin_amdgcn_readfirstlane(sm.type_info[t]);
+            const int hv = info & 15, hrc = (info >> 4) & 15;
+            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride),
+                                                        (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull,
+                                                        T.size_factor, lane, hrc, ep.ngen);
+            if (hr >= 0) { cell = hr & 0xFFFF; ep.chunks += hr >> 16; m03v = sm.hres[1].m03; placed = true; between(); }
+          }
+        }
+        if (!placed) {
 #ifdef EG_STAMPS
-        double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq, stamps));
-        stamps[11] += 1;
+          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq, stamps));
+          stamps[11] += 1;
 #else
-        double m03v = 0.0;
-        const int cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq));
+          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq));
 #endif
+        }
         EG_T1(1);
         if (cell < 0) { ep.status = cell == kSearchLost ? EG_EP_INTERNAL : EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         EG_MARKG(21);
@@ -1341,6 +1611,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
+        if constexpr (kHeavy) if (ep.heavy >= 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), heavy_reaches, lane, cell);
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
@@ -1466,6 +1737,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 #ifdef EG_STAMPS
     EG_MARKG(26);
     stamps[7] = __builtin_readcyclecounter() - t_begin;
+    if constexpr (kHeavy) {      // heavy searches: scan / candidates + records / exact evaluation / field update cycles; chunks, candidates, searches
+      stamps[27] = sm.hdbg[0][0]; stamps[28] = sm.hdbg[0][1]; stamps[29] = sm.hdbg[0][2]; stamps[30] = sm.hdbg[0][3];
+      stamps[24] = sm.hdbg[1][0]; stamps[25] = sm.hdbg[1][1]; stamps[26] = sm.hdbg[1][2];
+    }
     // where did this workgroup run?  HW_ID (se / sh / cu / simd / wave slot) and XCC_ID: more workgroups on one CU than fit
     // at once means some of them had to wait for a slot (second round) — scripts/bench_tail.py
     stamps[31] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -1855,18 +2130,40 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 
 }  // namespace
 
-int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, void* stream,
-                   bool helper_waves, void* ev_start, void* ev_stop) {
-  if (n == 0) return 0;
+namespace {
+template <bool kHeavy>
+void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
+                    const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const EpisodeMap& map, void* stream, void* ev0, void* ev1) {
   // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
   if (helper_waves)
-    hipExtLaunchKernelGGL(k_rollout<kHelperWaves>, dim3(n), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
-                          (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0, t, s, o, (unsigned long long)seed,
-                          (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
+    hipExtLaunchKernelGGL((k_rollout<kHelperWaves, kHeavy>), dim3(map.count), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
+                          (hipEvent_t)ev0, (hipEvent_t)ev1, 0, t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n,
+                          d_replay_mask, replay_period, d_stats, map);
   else
-    hipExtLaunchKernelGGL(k_rollout<0>, dim3(n), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev_start, (hipEvent_t)ev_stop, 0,
-                          t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats);
+    hipExtLaunchKernelGGL((k_rollout<0, kHeavy>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
+                          t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map);
+}
+}  // namespace
+
+int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
+                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& p) {
+  if (n == 0) return 0;
+  if (p.n_heavy > 0) {      // first, so that the long episodes start first
+    EpisodeMap m{};
+    m.count = p.n_heavy;
+    if (p.n_lean == 0) m.mode = 0u;
+    else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index; }
+    else { m.mode = 2u; m.off = p.off; m.period = p.period; }
+    launch_variant<true>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, p.ev[0], p.ev[1]);
+  }
+  if (p.n_lean > 0) {
+    EpisodeMap m{};
+    m.count = p.n_lean;
+    if (p.n_heavy == 0) m.mode = 0u;
+    else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index + p.n_heavy; }
+    else { m.mode = 3u; m.off = p.off; m.period = p.period; }
+    launch_variant<false>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_lean, p.ev[2], p.ev[3]);
+  }
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,

@@ -1,0 +1,27 @@
+"""Diagnostic: where does a heavy (replay) episode spend its cycles?  -DEG_STAMPS build (make -C eirgrid_amd/csrc stamps):
+   EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/heavy_stamps.py [per_year]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from eirgrid_amd import synthetic_world
+from eirgrid_amd.engine import ActionWeights, Engine
+per_year = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1638
+rng = np.random.default_rng(11)
+pol = ActionWeights()
+run = [[int(3 * rng.choice([0, 4, 12, 7]) + rng.integers(0, 3)) for _ in range(per_year)] for _ in range(26)]
+nr = np.array([len(l) for l in run], np.int32); nd = np.zeros(26, np.int32)
+pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.array([a for l in run for a in l], np.uint8), nd, np.zeros(0, np.uint8))
+eng = Engine(synthetic_world())
+mask = np.ones(n, np.uint8)
+res = eng.rollout_batch(pol, 321, n, replay_mask=mask)
+ms, k = eng.timing_read()
+st = res.act_log[:, -256:].copy().view(np.uint64).astype(np.float64)
+tot = st[:, 7].mean()
+print(f"{n} replay episodes, {res.n_gens.mean():.0f} generators each, status ok {int((res.status == 0).sum())}; kernel {ms / max(k, 1):.2f} ms; mean episode cycles {tot:.0f}")
+srch = st[:, 26].mean()
+for name, col in (("placement (all searches incl. exact-scan ones)", 1), ("bookkeeping after a search (incl. field update)", 12), ("sampling / replay pick", 2),
+                  ("year start aggregates", 0), ("yearly metrics", 4)):
+    print(f"  {name:48s} {st[:, col].mean():12.0f} cycles {100 * st[:, col].mean() / tot:5.1f} %")
+print(f"  heavy searches per episode {srch:.0f}: scan {st[:, 27].mean() / srch:.0f} cyc/search, candidates+records {st[:, 28].mean() / srch:.0f}, exact evaluation {st[:, 29].mean() / srch:.0f}, "
+      f"field update {st[:, 30].mean() / max(res.n_gens.mean(), 1):.0f} cyc/add; chunks scanned/search {st[:, 24].mean() / srch:.1f}, candidates/search {st[:, 25].mean() / srch:.2f}")

@@ -409,3 +409,58 @@ eng.close()
     n_internal, n_ok, seconds = int(res[2]), int(res[3]), float(res[4])
     assert n_internal + n_ok == 256 and n_internal >= 50 and seconds < 60
     assert [l for l in r.stdout.splitlines() if l.startswith("BIG")][0].split()[1] == "2048"
+
+
+def test_heavy_episodes_match_the_oracle(world):
+    """Replay episodes with hundreds of generators (what the reference's replay phase grows into).  From 64
+    generators on a search runs through the approximate penalty field + exact evaluation of the few candidates
+    (eg_rollout.hip place_heavy) instead of the exact branch-and-bound scan.  Every output must stay bit-identical: to the
+    tabled oracle, between the two kernels, and between a pool of field slots that covers every heavy episode, one that
+    runs out after three (the rest fall back to the exact scan) and no pool at all."""
+    tb = _tabled(world)
+    rng = np.random.default_rng(11)
+    policies = []
+    for per_year, types in ((12, list(range(15))), (9, [0, 4, 12]), (15, [1, 13, 14, 5, 7]), (17, [12])):
+        pol = ActionWeights()
+        run = [[int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(per_year)] for _ in range(26)]
+        dfl = [[int(3 * rng.choice([8, 7, 12, 11])) for _ in range(int(rng.integers(0, 3)))] for _ in range(26)]
+        nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
+        pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.array([a for l in run for a in l], np.uint8), nd,
+                          np.array([a for l in dfl for a in l], np.uint8))
+        policies.append(pol)
+    n = 96
+    mask = (np.arange(n) % 3 != 1).astype(np.uint8)
+    results, kernel_ms = {}, {}
+    for mode, slots in (("0", None), ("all", None), ("0", "3"), ("0", "0"), ("all", "0")):
+        os.environ["EIRGRID_HELPER_WAVES"] = mode
+        if slots is not None:
+            os.environ["EIRGRID_HEAVY_SLOTS"] = slots
+        try:
+            eng = Engine(world, device=0)
+        finally:
+            del os.environ["EIRGRID_HELPER_WAVES"]
+            os.environ.pop("EIRGRID_HEAVY_SLOTS", None)
+        try:
+            eng.timing_reset()
+            results[(mode, slots)] = [eng.rollout_batch(pol, 321 + k, n, first_episode_index=40 * k, replay_mask=mask) for k, pol in enumerate(policies)]
+            kernel_ms[(mode, slots)] = eng.timing_read()[0]
+        finally:
+            eng.close()
+    ref_runs = results[("0", None)]
+    heavy = 0
+    for k, pol in enumerate(policies):
+        a = ref_runs[k]
+        assert (a.status == 0).all(), (k, np.bincount(-a.status))
+        heavy += int((a.n_gens >= 200).sum())
+        for key, runs in results.items():
+            b = runs[k]
+            for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved",
+                         "run_log", "def_log", "act_log", "gen_cell", "gen_pack", "off_pack"):
+                assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (k, key, name)
+        for e in list(range(0, n, 7)) + [2, 5]:
+            st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 321 + k + 40 * k + e, replay=bool(mask[e]))
+            assert_episode_equal(a, e, ref, f"policy {k}, {'replay' if mask[e] else 'sampled'}")
+    assert heavy >= 100
+    # the field path really ran: the same episodes take a fraction of the exact scan's time
+    print("k_rollout ms for the four batches:", {f"{k[0]}/{k[1]}": round(v, 2) for k, v in kernel_ms.items()})
+    assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
