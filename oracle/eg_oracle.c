@@ -947,7 +947,7 @@ static uint32_t sample_additional_actions(og_weights *p, int yi) { /* sampling.r
 /* ------------------------------------------------------------------------- */
 /* apply_action (core/actions.rs:40-204)                                       */
 /* ------------------------------------------------------------------------- */
-typedef struct { og_episode_out *out; int overflow; } rec_t;
+typedef struct { og_episode_out *out; int overflow; int trip_cap; double *remaining_log; int *active_log; } rec_t;  /* trip_cap: og_delay_deficit_probe only */
 
 static void map_add_generator(map_t *m, gen_t g, rec_t *rec, int mult_idx) { /* map_handler.rs:553-709 */
   int current_year = m->current_year; double public_opinion = 0.65; /* :1518-1522 */
@@ -1057,6 +1057,11 @@ static void handle_power_deficit(map_t *m, double deficit, int yi, og_weights *p
       update_weights(p, action, yi, overall * 0.5);
       remaining = -mind(new_state.power_balance, 0.0);
     }
+    if (rec->trip_cap) { /* og_delay_deficit_probe: what the loop has achieved after this trip */
+      int active = 0; for (int g = 0; g < m->ngens; ++g) active += gen_is_active(&m->gens[g]);
+      rec->remaining_log[attempts - 1] = remaining; rec->active_log[attempts - 1] = active;
+      if ((int)attempts >= rec->trip_cap) { rec->overflow = 3; return; }
+    }
     if (rec->overflow) return;
   }
   action_result final_state = map_state(m, year);
@@ -1101,7 +1106,7 @@ static void yearly_metrics(const map_t *m, int year, int enable_energy_sales, co
 int32_t og_run_episode(const og_world *w, og_weights *weights, int32_t replay_best_strategy, uint64_t seed,
                        int32_t enable_energy_sales, int32_t enable_construction_delays, og_episode_out *out) {
   memset(out, 0, sizeof(*out));
-  rec_t rec = {out, 0};
+  rec_t rec = {out, 0, 0, 0, 0};
   /* run_iteration: iteration.rs:24-42 */
   map_t map; map_init(&map, w);
   for (int y = 0; y < OG_YEARS; ++y) { list_clear(&weights->cur_run[y]); list_clear(&weights->cur_def[y]); weights->replay_idx[y] = 0; weights->replay_def_idx[y] = 0; }
@@ -1240,6 +1245,29 @@ void og_post_episode_update(og_weights *shared, const og_weights *local, const d
   apply_contrast_learning(shared, metrics, &noise);
   update_best_strategy(shared, metrics);
   apply_deficit_contrast_learning(shared, &noise);
+}
+
+/* N4 evidence: the 2025 repair loop of simulation.rs:319-522 with
+ * enable_construction_delays = true, stopped after `trips` iterations.  Every plant the loop adds starts "Planned"
+ * (generator.rs:451-480), is_active() is false until it is Operational (generator.rs:519-521), so the added output is 0
+ * and remaining_deficit never moves: the reference's `while remaining_deficit > 0.0` (simulation.rs:359) does not end. */
+int32_t og_delay_deficit_probe(const og_world *w, int32_t trips, double *remaining_after_trip, int32_t *active_after_trip,
+                               double *initial_deficit, int32_t *plants_added) {
+  og_episode_out *out = (og_episode_out *)calloc(1, sizeof(*out));
+  rec_t rec = {out, 0, trips, remaining_after_trip, active_after_trip};
+  map_t map; map_init(&map, w);
+  og_weights *p = og_weights_new();
+  rng_seed(&p->rng, 12345); p->has_rng = 1;
+  map.enable_delays = 1; map.current_year = OG_BASE_YEAR;
+  map_update_construction_status(&map);
+  action_result s0 = map_state(&map, OG_BASE_YEAR);
+  *initial_deficit = -s0.power_balance;
+  int before = map.ngens;
+  if (s0.power_balance < 0.0) handle_power_deficit(&map, -s0.power_balance, 0, p, &rec);
+  *plants_added = map.ngens - before;
+  int status = rec.overflow;
+  og_weights_free(p); map_free(&map); free(out);
+  return status; /* 3: stopped by the trip cap with the deficit still open */
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1586,7 +1614,7 @@ static void thandle_power_deficit(tmap_t *m, og_weights *p, rec_t *rec) {
 int32_t og_run_episode_tabled(const og_tables *T, og_weights *p, int32_t replay, uint64_t seed, int32_t enable_energy_sales,
                               og_episode_out *out) {
   memset(out, 0, sizeof(*out));
-  rec_t rec = {out, 0};
+  rec_t rec = {out, 0, 0, 0, 0};
   tmap_t m; memset(&m, 0, sizeof(m));
   m.T = T; m.gens = (tgen_t *)malloc(sizeof(tgen_t) * OG_LOG_CAP); m.offs = (toff_t *)malloc(sizeof(toff_t) * OG_LOG_CAP);
   m.fld = (double *)malloc(sizeof(double) * 2601);

@@ -77,8 +77,9 @@ def test_readme_demand_columns(built):
     """The Pop. and Power Usage columns of the reference README are exact known answers of the demand step for the
     reference's own settlements.json.  That asset is not redistributable, so it is read in place when present."""
     path = "/root/reference/aiSimulator/assets/settlements.json"
-    if not os.path.exists(path):
-        pytest.skip("reference assets are not present on this machine")
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("no /root/reference on this machine (the GPU box): the pin runs in the build container")
+    assert os.path.exists(path), "the build container must have the reference's settlements.json: this is the oracle's only reference-held pin"
     from eirgrid_amd.world import World
     pops = [s["population"] for s in json.load(open(path))["settlements"]]
     n = len(pops)
@@ -136,3 +137,17 @@ def test_placement_properties(oracle_world):
     assert score_off < score_on    # same radius class; the coast factor 1/(1+d/5000) < 1 only applies offshore
     # populations grow every year, so the settlement factor and the best score grow too
     assert oracle_world.place(10, 8)[1] > score
+
+
+def test_construction_delays_never_close_the_2025_deficit(oracle_world):
+    """N4 evidence: with --enable-construction-delays every plant the 2025 repair loop adds is
+    'Planned' (generator.rs:451-480) and is_active() is false until 'Operational' (generator.rs:519-521), so the loop's
+    `while remaining_deficit > 0.0` (simulation.rs:359) adds plant after plant without moving the deficit: the reference
+    mode does not terminate.  The literal oracle, stopped after 16 trips: 16 plants added, 0 active, deficit unchanged."""
+    status, deficit0, remaining, active, added = O.delay_deficit_probe(oracle_world, 16)
+    assert status == 3 and added == 16
+    assert deficit0 > 5000.0                      # 2025: all existing plant is still "Planned" (Q1)
+    assert (remaining == deficit0).all() and (active == 0).all()
+    # the same world without delays closes the deficit in 2025 (config 1's episode finishes)
+    st, out = O.run_episode(oracle_world, O.OracleWeights(), 12345)
+    assert st == 0 and out.yearly[0][4] >= 0.0
