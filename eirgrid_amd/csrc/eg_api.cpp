@@ -280,6 +280,20 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         }
       }
   }
+  {  // heavy episodes (eg_rollout.hip heavy_add): every (class, di, dj) with a factor below 1, i.e. closer than the class radius
+    uint32_t* box = reinterpret_cast<uint32_t*>(blob.data() + tab::hv_box);
+    int nbox = 0;
+    for (int k = 0; k < kRadiusClasses; ++k)
+      for (int di = -kMaxReach; di <= kMaxReach; ++di)
+        for (int dj = -kMaxReach; dj <= kMaxReach; ++dj) {
+          const int ai = di < 0 ? -di : di, aj = dj < 0 ? -dj : dj;
+          if (H.dr[(size_t(k) * 13 + ai) * 13 + aj] == 1.0) continue;
+          if (nbox < 1024) box[nbox] = uint32_t(di + 16) | (uint32_t(dj + 16) << 5) | (uint32_t(di * di + dj * dj) << 10) | (uint32_t(k) << 18);
+          ++nbox;
+        }
+    if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
+    for (int i = nbox; i < 1024; ++i) box[i] = 7u << 18;
+  }
   if (rc == EG_OK) {
     void* p = nullptr;
     if (hipMalloc(&p, tab::total) != hipSuccess) { set_error("hipMalloc(tables) failed"); rc = EG_ERR_HIP; }

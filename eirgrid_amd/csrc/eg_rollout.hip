@@ -910,7 +910,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 // exact scores (and every cell tied with it) therefore lies within 2^-41 of M and is among the candidates, and a cell
 // below the threshold cannot reach the exact score of M's holder.  Subnormal ranges (M < 1e-250), more than 64
 // candidates, or no free field slot fall back to the exact scan above.  Results are the exact scan's, bit for bit.
-constexpr int kHeavyGens = 64;
+constexpr int kHeavyGens = 8;       // (the heavy variant only runs replay episodes: their exact scans go deep almost at once)
 constexpr int kFieldStride = 2624;                   // doubles per radius class of a field slot
 constexpr int kSearchFallback = -3;
 // The three functions below are not inlined (they would cost the episode loop its registers), and a pointer that crosses a
@@ -935,80 +935,97 @@ __device__ __forceinline__ double factor_by_q(int rc, int q) {
   else return sm.dr[rc * kD2Stride + q];
 }
 // one slot of the pool for this launch, or -2 (pool exhausted / absent).  The claim word holds launch epoch << 20 | count,
-// so no launch has to reset it.
+// so no launch has to reset it: the first claim of a launch swaps the new epoch in with a zero count, every claim is then
+// ONE fetch-and-add (a compare-and-swap loop here made 1 638 episodes queue behind each other for milliseconds).
 __device__ __forceinline__ int heavy_claim(const DevTables& T, int lane) {
   int slot = -2;
   if (lane == 0 && T.heavy != nullptr) {
     unsigned* w = T.heavy_claim;
     const unsigned epoch = T.heavy_epoch & 0xFFFu;
-    unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int guard = 0; guard < 1000000; ++guard) {
-      unsigned desired, mine;
-      if ((old >> 20) != epoch) { desired = (epoch << 20) | 1u; mine = 0u; }
-      else { mine = old & 0xFFFFFu; if (mine >= T.heavy_slots) break; desired = old + 1u; }
-      const unsigned prev = atomicCAS(w, old, desired);
-      if (prev == old) { slot = (int)mine; break; }
-      old = prev;
-    }
+    const unsigned old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 20) != epoch) atomicCAS(w, old, epoch << 20);      // whoever comes first; a failure means somebody else did it
+    const unsigned v = atomicAdd(w, 1u);
+    if ((v >> 20) == epoch && (v & 0xFFFFFu) < T.heavy_slots) slot = (int)(v & 0xFFFFFu);
   }
   return __builtin_amdgcn_readfirstlane(slot);
 }
-// field[rc][c] *= d/R of a generator at `cell`, for every class and every cell within reach (`reaches`: 4 bits per class).
-// The whole update is ONE memory round trip: every lane first requests all the entries it will touch (kFieldOps[rc]
-// blocks of 64 cells cover the (2 reach + 1)^2 box of class rc: reach 11, 7, 4, 6, 5, 2 cells for the reference's radii of
-// 12, 8, 5, 7, 6, 3 km in the class order of eg_tables.cpp — heavy_ops_fit checks that), then multiplies and stores.
-// Entries are distinct, so the order is free.
-constexpr int kFieldOps[kRadiusClasses] = {9, 4, 2, 3, 2, 1};
-constexpr int kFieldOpsTotal = 21;
-__device__ __forceinline__ bool heavy_ops_fit(int reaches) {
-  bool ok = true;
-  for (int rc = 0; rc < kRadiusClasses; ++rc) { const int w = 2 * ((reaches >> (4 * rc)) & 15) + 1; ok = ok && (w * w <= kWave * kFieldOps[rc]); }
-  return ok;
+// field[rc][c] *= d/R of a generator at `cell`, for every class and every cell closer than the class radius.  The cells
+// concerned are the same for every generator up to a translation: the host lists them once (eg_api.cpp, tab::hv_box: 978
+// entries {di, dj, squared distance, class} for the reference's six radii, padded to 1024 = 16 per lane) and the heavy
+// variant keeps the list in LDS.  One memory round trip: every lane requests its (at most) 16 field entries, then
+// multiplies and stores.  Entries are distinct, so the order is free.  A wave costs four cycles per instruction whatever
+// it does, so this is written for instruction count: the list spares the index arithmetic of walking six boxes.
+constexpr int kBoxEntries = 1024, kBoxPerLane = kBoxEntries / kWave;
+struct __align__(16) SmemHeavy { uint32_t box[kBoxEntries]; };      // di + 16 | (dj + 16) << 5 | q << 10 | class << 18 (class 7: padding)
+__shared__ SmemHeavy sh;
+__device__ __forceinline__ void load_heavy_tables(const DevTables& T, int lane) {
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(T.base + tab::hv_box);
+  for (int i = lane; i < kBoxEntries; i += kWave) sh.box[i] = src[i];
 }
 template <bool kLatency>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int reaches, int lane, int cell) {
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
   const int gi = cell / kGrid, gj = cell - gi * kGrid;
-  double val[kFieldOpsTotal], fac[kFieldOpsTotal]; int off[kFieldOpsTotal];
-  int slot = 0;
+  const GlobalF64 base = (GlobalF64)field_addr;
+  double val[kBoxPerLane], fac[kBoxPerLane]; int off[kBoxPerLane];
 #pragma unroll
-  for (int rc = 0; rc < kRadiusClasses; ++rc) {
-    const int reach = (reaches >> (4 * rc)) & 15;
-    const int w = 2 * reach + 1, n = w * w;
-    const float inv_w = 1.0f / (float)w;
-    const GlobalF64 f = (GlobalF64)(field_addr + (unsigned long long)(rc * kFieldStride) * 8ull);
-#pragma unroll
-    for (int k = 0; k < kFieldOps[rc]; ++k, ++slot) {
-      const int idx = lane + kWave * k;
-      const int row = (int)(((float)idx + 0.5f) * inv_w);      // idx / w, exact for idx < 625, w <= 25
-      const int di = row - reach, dj = idx - row * w - reach;
-      const int ci = gi + di, cj = gj + dj;
-      off[slot] = -1; fac[slot] = 1.0; val[slot] = 1.0;
-      if (idx < n && ci >= 0 && ci < kGrid && cj >= 0 && cj < kGrid) {
-        int q = di * di + dj * dj; q = q < kD2Max ? q : kD2Max;
-        fac[slot] = factor_by_q<kLatency>(rc, q);
-        if (fac[slot] != 1.0) { off[slot] = rc * kFieldStride + ci * kGrid + cj; val[slot] = field_load(f + (ci * kGrid + cj)); }
-      }
+  for (int k = 0; k < kBoxPerLane; ++k) {
+    const uint32_t en = sh.box[k * kWave + lane];
+    const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 18);
+    off[k] = -1; fac[k] = 1.0; val[k] = 1.0;
+    if (rc < kRadiusClasses && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {
+      fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
+      off[k] = rc * kFieldStride + ci * kGrid + cj;
+      val[k] = field_load(base + off[k]);
     }
   }
-  const GlobalF64 base = (GlobalF64)field_addr;
 #pragma unroll
-  for (int k = 0; k < kFieldOpsTotal; ++k)
+  for (int k = 0; k < kBoxPerLane; ++k)
     if (off[k] >= 0) base[off[k]] = val[k] * fac[k];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores are in L2 before anything gathers from the field
+  // (the stores are left in flight: whoever reads the field next — place_heavy, heavy_enter's loop — waits for them first)
 #ifdef EG_STAMPS
   if (lane == 0) sm.hdbg[0][3] += __builtin_readcyclecounter() - ts0;
 #endif
 }
 // the episode turns heavy: all ones, then every generator placed so far
 template <bool kLatency>
-__device__ __noinline__ void heavy_enter(unsigned long long field_addr, int reaches, int lane, int ngen) {
+__device__ __noinline__ void heavy_enter(unsigned long long field_addr, int lane, int ngen) {
   const GlobalF64 f = (GlobalF64)field_addr;
   for (int i = lane; i < kRadiusClasses * kFieldStride; i += kWave) f[i] = 1.0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int g = 0; g < ngen; ++g) heavy_add<kLatency>(field_addr, reaches, lane, (int)(sm.gcell[g] & 0xFFF));
+  for (int g = 0; g < ngen; ++g) {
+    heavy_add<kLatency>(field_addr, lane, (int)(sm.gcell[g] & 0xFFF));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next generator's box may overlap this one's
+  }
+}
+// The reference's product for ONE candidate cell: te times the factor of every generator in list order.  The lanes take a
+// generator each for the factors (64 at a time); the product itself is the sequential chain, three instructions per
+// generator (two v_readlane, one v_mul_f64) against the six or seven of chunk_product, which evaluates 64 candidates at
+// once — and a heavy search has one candidate, rarely two.
+template <bool kLatency>
+__device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double te, int cell, int lane) {
+  const int ci = cell / kGrid, cj = cell - ci * kGrid;
+  double s = te;
+  for (int gb = 0; gb < ngen_s; gb += kWave) {
+    double f = 1.0;
+    if (gb + lane < ngen_s) {
+      const int gc = (int)(sm.gcell[gb + lane] & 0xFFF);
+      const int gi = gc / kGrid, gj = gc - gi * kGrid;
+      int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
+      q = q < kD2Max ? q : kD2Max;
+      f = factor_by_q<kLatency>(rc, q);
+    }
+    const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+    int j = 0;
+    for (; j + 4 <= cnt; j += 4) {
+      const double f0 = readlane_f64(f, j), f1 = readlane_f64(f, j + 1), f2 = readlane_f64(f, j + 2), f3 = readlane_f64(f, j + 3);
+      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+    }
+    for (; j < cnt; ++j) s = s * readlane_f64(f, j);
+  }
+  return s;
 }
 // `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
 // returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
@@ -1017,6 +1034,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last field update's stores are in L2 before anything gathers
   const GlobalF64 A = (GlobalF64)class_addr;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;      // 41: the list holds exactly kChunks * 64 records
@@ -1028,6 +1046,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   //    so whatever is within 2^-30 of the final M was so then.  A third one (ties en masse) sends the search to pass 2.
   double M = 0.0; int K = 0;
   double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
+  double q1te = 0.0, q1cf = 1.0, q1m03 = 0.0; int q1cell = 0;      // the record of q1 stays with it: the usual single candidate needs no second load
   PsRec c[kGroup], nx[kGroup];
 #pragma unroll
   for (int j = 0; j < kGroup; ++j) c[j] = load_rec(list_addr, j * kWave + lane);
@@ -1053,7 +1072,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
     for (int j = 0; j < kGroup; ++j)
       if (ap[j] >= thr_now && ap[j] > 0.0) {
         const int rank = (g * kGroup + j) * kWave + lane;
-        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; }
+        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1te = c[j].te; q1cf = c[j].cf; q1m03 = c[j].m03; q1cell = (int)c[j].cell; }
         else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
         else over = true;
       }
@@ -1067,9 +1086,10 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
 #endif
   // 2. the candidates: everything within 2^-30 of M
   const double thr = M * kKeep;
-  int ncand = 0;
+  int ncand = 0, solo = -1;      // solo: the lane whose q1 is the only candidate
   if (__ballot(over) == 0ull) {
     const unsigned long long m1 = __ballot(q1r >= 0 && q1v >= thr), m2 = __ballot(q2r >= 0 && q2v >= thr);
+    if (m2 == 0ull && __popcll(m1) == 1) solo = __ffsll((long long)m1) - 1;
     const unsigned long long below = (1ull << lane) - 1ull;
     const int n1 = __popcll(m1);
     if ((m1 >> lane) & 1ull) sm.gstage[1][__popcll(m1 & below)] = q1r;
@@ -1091,16 +1111,31 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   if (ncand > kWave || ncand == 0) return kSearchFallback;
   wave_sync();
   // 3. exact scores of the candidates: the reference's product in list order, first maximum in cell order
-  const int r = lane < ncand ? sm.gstage[1][lane] : kCells;
-  PsRec e; e.te = 0.0; e.cf = 1.0; e.m03 = 0.0; e.cell = 0u; e.pad = 0u;
-  if (r < kCells) e = load_rec(list_addr, r);
 #ifdef EG_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long ts2 = __builtin_readcyclecounter();
 #endif
-  const int table = kLatency ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
-  const double s = chunk_score<kLatency>(table, size_factor, lane, ngen_s, r, e.te, e.cf, (int)e.cell, (int)e.pad);
-  const ChunkBest b = chunk_reduce<false>(s, (int)e.cell, e.m03);
+  ChunkBest b; b.score = 0.0; b.m03 = 0.0; b.cell = kCells;
+  if (ncand == 1 && solo >= 0) {      // the usual case: one candidate, its record still in the lane that found it
+    const double te1 = readlane_f64(q1te, solo), cf1 = readlane_f64(q1cf, solo);
+    const int cell1 = __builtin_amdgcn_readlane(q1cell, solo);
+    b.score = (exact_product_chain<kLatency>(rc, ngen_s, te1, cell1, lane) * cf1) * size_factor;
+    b.cell = cell1; b.m03 = readlane_f64(q1m03, solo);
+  } else if (ncand <= 4) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
+    for (int k = 0; k < ncand; ++k) {
+      const int rk = __builtin_amdgcn_readfirstlane(sm.gstage[1][k]);
+      const PsRec e = load_rec(list_addr, rk);      // the same record in every lane
+      const double sk = (exact_product_chain<kLatency>(rc, ngen_s, e.te, (int)e.cell, lane) * e.cf) * size_factor;
+      if (sk > b.score || (sk == b.score && sk > 0.0 && (int)e.cell < b.cell)) { b.score = sk; b.cell = (int)e.cell; b.m03 = e.m03; }
+    }
+  } else {               // many ties: 64 candidates at once (chunk_product)
+    const int r = lane < ncand ? sm.gstage[1][lane] : kCells;
+    PsRec e; e.te = 0.0; e.cf = 1.0; e.m03 = 0.0; e.cell = 0u; e.pad = 0u;
+    if (r < kCells) e = load_rec(list_addr, r);
+    const int table = kLatency ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
+    const double s = chunk_score<kLatency>(table, size_factor, lane, ngen_s, r, e.te, e.cf, (int)e.cell, (int)e.pad);
+    b = chunk_reduce<false>(s, (int)e.cell, e.m03);
+  }
   if (!(b.score > 0.0)) return kSearchFallback;
 #ifdef EG_STAMPS
   if (lane == 0) { sm.hdbg[0][0] += ts1 - ts0; sm.hdbg[0][1] += ts2 - ts1; sm.hdbg[0][2] += __builtin_readcyclecounter() - ts2; sm.hdbg[1][0] += (unsigned long long)K; sm.hdbg[1][1] += (unsigned long long)ncand; sm.hdbg[1][2] += 1ull; }
@@ -1322,8 +1357,10 @@ __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b)
   return m.off + (q / p1) * m.period + 1u + q % p1;
 }
 
+// (the heavy variant trades occupancy for registers: two waves per SIMD, 256 VGPRs — its grid is the few long episodes,
+//  which are bound by their own serial latency, and the field code inlines without spilling)
 template <int kHelpers, bool kHeavy>
-__global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
                                                                     const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
                                                                     long long* stats, EpisodeMap emap) {
@@ -1332,7 +1369,6 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
   const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
   uint32_t search_seq = 0, year_seq = 0;      // commands to the helper wave share one sequence
-  int heavy_reaches = 0;                      // heavy episodes: reach of the six radius classes, four bits each
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1363,7 +1399,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
 #ifdef EG_STAMPS
   if (kHeavy && lane < 8) sm.hdbg[lane >> 2][lane & 3] = 0ull;
 #endif
-  load_static_tables(T, lane, kHelpers == 0);
+  load_static_tables(T, lane, kHelpers == 0 || kHeavy);      // (the heavy variant's field update reads sm.dr / sl.dr16)
+  if constexpr (kHeavy) load_heavy_tables(T, lane);
   // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
   const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
                                                  T.pre_tg()[lane] == T.pre_tg()[lane - 1] && T.pre_ig()[lane] == T.pre_ig()[lane - 1] &&
@@ -1566,21 +1603,25 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
           const unsigned long long slot_bytes = (unsigned long long)(kRadiusClasses * kFieldStride) * 8ull;
           if (ep.heavy == -1) {
             ep.heavy = heavy_claim(T, lane);
-            if (ep.heavy >= 0) {
-              heavy_reaches = 0;
-              for (int k = 0; k < kRadiusClasses; ++k) heavy_reaches |= (T.reach()[k] & 15) << (4 * k);
-              heavy_reaches = __builtin_amdgcn_readfirstlane(heavy_reaches);
-              if (!heavy_ops_fit(heavy_reaches)) ep.heavy = -2;      // other radii than the reference's: exact scans only
-              else heavy_enter<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes, heavy_reaches, lane, ep.ngen);
-            }
+            if (ep.heavy >= 0) heavy_enter<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes, lane, ep.ngen);
           }
           if (ep.heavy >= 0) {
             const int info = __builtin_amdgcn_readfirstlane(sm.type_info[t]);
             const int hv = info & 15, hrc = (info >> 4) & 15;
+#ifdef EG_STAMPS
+            const unsigned long long th0 = __builtin_readcyclecounter();
+#endif
             const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride),
                                                         (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull,
                                                         T.size_factor, lane, hrc, ep.ngen);
+#ifdef EG_STAMPS
+            const unsigned long long th1 = __builtin_readcyclecounter();
+            stamps[9] += th1 - th0;
+#endif
             if (hr >= 0) { cell = hr & 0xFFFF; ep.chunks += hr >> 16; m03v = sm.hres[1].m03; placed = true; between(); }
+#ifdef EG_STAMPS
+            stamps[10] += __builtin_readcyclecounter() - th1;
+#endif
           }
         }
         if (!placed) {
@@ -1611,7 +1652,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), 3) k_rollout(DevTables
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
-        if constexpr (kHeavy) if (ep.heavy >= 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), heavy_reaches, lane, cell);
+        if constexpr (kHeavy) if (ep.heavy >= 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), lane, cell);
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)

@@ -240,7 +240,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "h", None):
-            N.lib().eg_destroy(self.h)
+            try:
+                N.lib().eg_destroy(self.h)
+            except TypeError:      # interpreter shutdown: module globals are already gone
+                pass
             self.h = None
 
     __del__ = close

@@ -25,3 +25,4 @@ for name, col in (("placement (all searches incl. exact-scan ones)", 1), ("bookk
     print(f"  {name:48s} {st[:, col].mean():12.0f} cycles {100 * st[:, col].mean() / tot:5.1f} %")
 print(f"  heavy searches per episode {srch:.0f}: scan {st[:, 27].mean() / srch:.0f} cyc/search, candidates+records {st[:, 28].mean() / srch:.0f}, exact evaluation {st[:, 29].mean() / srch:.0f}, "
       f"field update {st[:, 30].mean() / max(res.n_gens.mean(), 1):.0f} cyc/add; chunks scanned/search {st[:, 24].mean() / srch:.1f}, candidates/search {st[:, 25].mean() / srch:.2f}")
+print(f"  around the place_heavy call {st[:, 9].mean() / srch:.0f} cyc/search, between() {st[:, 10].mean() / srch:.0f}")
