@@ -41,6 +41,7 @@ struct Args {   // cli/cli.rs:5-59
   // engine-specific
   std::string world_json, assets_dir = "aiSimulator/assets"; uint32_t batch = 1024; std::string update = "reduced"; int device = 0;
   bool existing_operational_at_start = false;
+  uint64_t stop_after = 0;      // leave the loop (as an interrupt would) once this many iterations are done and checkpointed
 };
 
 void usage() {
@@ -54,7 +55,8 @@ void usage() {
             "engine options:\n      --world <FILE>       world in eirgrid_amd JSON form (default: read <assets-dir> like the reference)\n"
             "      --assets-dir <DIR>   settlements.json, ireland_generators.csv, coastline_points.json [default: aiSimulator/assets]\n"
             "      --batch <B>          iterations per GPU launch [default: 1024]\n      --update <sequential|reduced>  [default: reduced]\n"
-            "      --device <N>         [default: 0]\n      --existing-operational-at-start");
+            "      --device <N>         [default: 0]\n      --existing-operational-at-start\n"
+            "      --stop-after <N>     stop like an interrupted run once N iterations are done and checkpointed (resume tests)");
 }
 
 bool parse(int argc, char** argv, Args& a) {
@@ -89,6 +91,7 @@ bool parse(int argc, char** argv, Args& a) {
     else if (s == "--update") a.update = v();
     else if (s == "--device") a.device = std::atoi(v().c_str());
     else if (s == "--existing-operational-at-start") a.existing_operational_at_start = true;
+    else if (s == "--stop-after") a.stop_after = std::strtoull(v().c_str(), nullptr, 10);
     else if (s == "-h" || s == "--help") { usage(); std::exit(0); }
     else { std::fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage(); return false; }
   }
@@ -241,6 +244,7 @@ int main(int argc, char** argv) {
   auto t0 = std::chrono::steady_clock::now(); auto last_progress = t0;
   uint64_t done = start_iteration, last_checkpoint = start_iteration / a.checkpoint_interval;
   const bool reduced = a.update == "reduced";
+  unsigned failed_sequential = 0;      // --update sequential: episodes that did not finish (reduced mode counts them on the device)
   // reduced mode keeps the policy on the device: pushed once, every batch is enqueued without a host round trip and the
   // host copy is refreshed (eg_policy_pull) when a checkpoint or a progress line needs it
   if (reduced) CHECK(eg_policy_push(ctx, policy, &opts));
@@ -269,7 +273,8 @@ int main(int argc, char** argv) {
       CHECK(eg_fetch(ctx, &out));
       int best_in_batch = -1;
       for (uint32_t i = 0; i < n; ++i)   // multi_simulation.rs:494-508, in iteration order
-        if (status[i] == EG_EP_OK) {
+        if (status[i] != EG_EP_OK) failed_sequential += 1;
+        else {
           const double before = eg_policy_get_scalar(policy, 12);      // improvements recorded so far
           CHECK(eg_policy_apply_episode(policy, &metrics[size_t(i) * 4], &n_run[size_t(i) * EG_YEARS], &run_log[size_t(i) * EG_RUN_CAP],
                                         &n_def[size_t(i) * EG_YEARS], &def_log[size_t(i) * EG_DEF_CAP], a.seed + done + i));
@@ -293,11 +298,19 @@ int main(int argc, char** argv) {
       last_progress = now;
       const double secs = std::chrono::duration<double>(now - t0).count();
       double bm[4] = {eg_policy_get_scalar(policy, 5), eg_policy_get_scalar(policy, 6), eg_policy_get_scalar(policy, 7), eg_policy_get_scalar(policy, 8)};
-      std::printf("Progress: %llu/%llu iterations (%.1f%%), %.0f iterations/s | best score %.6f (emissions %.1f t, cost EUR %.2fB, opinion %.1f%%), %u without improvement\n",
+      // (failed: episodes that ran out of the per-episode capacities — replay-doubled lists; they are not part of
+      //  iteration_count and never silently dropped from the count)
+      std::printf("Progress: %llu/%llu iterations (%.1f%%), %.0f iterations/s | best score %.6f (emissions %.1f t, cost EUR %.2fB, opinion %.1f%%), %u without improvement, %u episodes failed\n",
                   (unsigned long long)done, (unsigned long long)a.iterations, 100.0 * double(done) / double(a.iterations),
                   double(done - start_iteration) / std::max(secs, 1e-9), eg_policy_get_scalar(policy, 4) != 0.0 ? eg_score_metrics(bm, a.cost_only ? 1 : 0) : 0.0,
-                  bm[0], bm[2] / 1e9, bm[1] * 100.0, unsigned(eg_policy_get_scalar(policy, 2)));
+                  bm[0], bm[2] / 1e9, bm[1] * 100.0, unsigned(eg_policy_get_scalar(policy, 2)), unsigned(eg_policy_get_scalar(policy, 13)) + failed_sequential);
       std::fflush(stdout);
+    }
+    if (a.stop_after && done >= a.stop_after && done < a.iterations) {
+      if (!checkpoint_due) { std::fprintf(stderr, "error: --stop-after needs a checkpoint at the stop (use -i 1 or a divisor)\n"); return 2; }
+      std::printf("Stopped after %llu iterations (--stop-after); resume with the same command\n", (unsigned long long)done);
+      eg_policy_free(policy); eg_destroy(ctx);
+      return 0;
     }
   }
   CHECK(eg_policy_save_json(policy, (run_dir + "/best_weights.json").c_str()));   // multi_simulation.rs:1160-1164
@@ -311,8 +324,8 @@ int main(int argc, char** argv) {
     if (best_run.valid) CHECK(eg_export_summary_csv(&best_run.view, (dir + "/simulation_summary.csv").c_str(), stamp));
     else std::puts("note: no improvement in this run; simulation_summary.csv not written");
   }
-  std::printf("Done: %llu iterations in %s; best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
-              (unsigned long long)done, run_dir.c_str());
+  std::printf("Done: %llu iterations in %s (%u episodes failed); best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
+              (unsigned long long)done, run_dir.c_str(), unsigned(eg_policy_get_scalar(policy, 13)) + failed_sequential);
   eg_policy_free(policy);
   eg_destroy(ctx);
   return 0;
