@@ -79,8 +79,11 @@ def pmc_traffic(workload: str):
     if not hit:
         return None
     cfg, name = hit
-    rows = cfg.get("fetch_rows") or []
-    dur = sum(r["dur_ns"] for r in rows) / len(rows) * 1e-9 if rows else None
+    if "kernel_ns" in cfg:
+        dur = cfg["kernel_ns"] * 1e-9
+    else:      # (profiles of round 1: one grid per launch)
+        rows = cfg.get("fetch_rows") or []
+        dur = sum(r["dur_ns"] for r in rows) / len(rows) * 1e-9 if rows else None
     return {"bytes": float(cfg["hbm_bytes_per_launch"]), "kernel_s": dur, "profile": name}
 
 
@@ -96,7 +99,11 @@ def sq_counters(workload: str):
         busy = run["SQ_ACTIVE_INST_VALU"] * 4.0 / (CUS * SIMDS_PER_CU * run["duration_ns"] * 1e-9 * clock_hz)
     except (KeyError, ZeroDivisionError):
         return None
-    return {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / max(run.get("episodes_per_launch", 1), 1)}
+    out = {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / max(run.get("episodes_per_launch", 1), 1)}
+    for v in ("heavy", "lean"):      # a batch with replay episodes: the two grids of the launch, measured one after the other
+        if isinstance(run.get(v), dict) and "valu_busy" in run[v]:
+            out[f"valu_busy_{v}_grid"] = run[v]["valu_busy"]
+    return out
 
 
 def cpu_baseline(world, seconds_budget: float = 20.0):
@@ -195,6 +202,7 @@ def roofline_object(workload, census, episodes, avg_kernel_s):
            "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
            "hbm_frac_measured": (tr["bytes"] / tr["kernel_s"] / 1e9 / HBM_PEAK_GBS) if tr and tr["kernel_s"] else None,
            "valu_busy": sq["valu_busy"] if sq else None,
+           "valu_busy_grids": {k[10:-5]: v for k, v in sq.items() if k.startswith("valu_busy_") and k.endswith("_grid")} if sq else None,
            "kernel": "k_rollout", "avg_kernel_ms": avg_kernel_s * 1e3,
            "touched_bytes_per_launch": touched, "touched_bytes_per_episode": touched / max(episodes, 1),
            "nominal_bytes_per_launch": nominal, "nominal_frac": nominal / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else 0.0,

@@ -1143,7 +1143,9 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   wave_sync();
   if (lane == 0) sm.hres[1].m03 = b.m03;
   wave_sync();
-  return b.cell | ((K + 1) << 16);      // (a second pass re-reads the first pass's records)
+  // requested, in units of 2 KB (= a chunk of 64 records): the K chunks scanned and the winner's chunk (a second pass re-reads
+  // the first pass's records), K x 64 field entries of 8 B, and the field update that follows (978 entries read and written)
+  return b.cell | ((K + 1 + (K + 3) / 4 + 8) << 16);
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------

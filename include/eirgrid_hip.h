@@ -135,9 +135,10 @@ typedef struct {
   uint16_t *off_pack;   /* [n][EG_MAX_OFFSETS] offset type | year index << 4 | multiplier index << 9 */
   uint64_t *n_draws;    /* [n] words consumed from the episode stream */
   double *bytes_moved;  /* [n] algorithmic bytes of the episode, SURVEY.md §8(d) formula (bills the whole 2601 x 8 B score field per search) */
-  uint32_t *n_chunks;   /* [n] 64-candidate chunks of sorted candidate records (32 B each) the episode's searches requested: what the
-                           branch-and-bound search really reads instead of the field; bytes touched = bytes_moved
-                           - n_gens * 2601 * 8 + n_chunks * 64 * 32 */
+  uint32_t *n_chunks;   /* [n] what the episode's placement searches requested from memory, in units of 2 KB: chunks of 64 sorted
+                           candidate records (32 B each) — what the branch-and-bound search reads instead of the score field —
+                           and, for long (replay) episodes, the entries of their penalty field (eg_rollout.hip place_heavy);
+                           bytes touched = bytes_moved - n_gens * 2601 * 8 + n_chunks * 2048 */
 } eg_episode_out;
 
 const char *eg_last_error(void);

@@ -30,5 +30,5 @@ rocprofv3 --pmc $SQ -d $O/sq_${tag}_c1 --output-format csv -- python3 bench.py $
 echo "sq counters done"
 python scripts/pmc_summarize.py $tag $O 16384r0.1:$O/pmc_${tag}_f_c2:$O/pmc_${tag}_w_c2 1024:$O/pmc_${tag}_f_c1:$O/pmc_${tag}_w_c1
 python scripts/sq_summarize.py $tag $O 16384r0.1:$O/sq_${tag}_c2 1024:$O/sq_${tag}_c1
-rm -rf $O/prof_${tag}_c1 $O/prof_${tag}_c2 $O/pmc_${tag}_* $O/sq_${tag}_*
+rm -rf $O/prof_${tag}_c1 $O/prof_${tag}_c2 $O/pmc_${tag}_f_* $O/pmc_${tag}_w_* $O/sq_${tag}_c1 $O/sq_${tag}_c2
 echo refreshed $tag
