@@ -75,8 +75,9 @@ struct eg_ctx {
   uint32_t* d_index = nullptr; uint32_t index_cap = 0;         // replay / other episode indices of a host-masked batch
   int ring_head = 0, ring_pending = 0;      // next pair to use; pairs recorded and not yet collected (the oldest is head - pending)
   double total_ms = 0.0; int32_t n_launches = 0;
-  // eg_place: device buffers kept between calls
+  // eg_place / eg_find_suitable_location: device buffers kept between calls
   uint16_t* d_place_cells = nullptr; int32_t* d_place_cell = nullptr; double* d_place_score = nullptr;
+  double* d_place_xy = nullptr; int32_t place_xy_cap = 0;
   uint32_t push_iteration_count = 0;     // iteration counter written into the device state by the next upload
   uint32_t push_failed = 0;              // ... and the failed-episode counter
   uint32_t pulled_improvements = 0;      // on-device improvement log entries already appended to a host policy
@@ -336,6 +337,7 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_place_cells) (void)hipFree(c->d_place_cells);
   if (c->d_place_cell) (void)hipFree(c->d_place_cell);
   if (c->d_place_score) (void)hipFree(c->d_place_score);
+  if (c->d_place_xy) (void)hipFree(c->d_place_xy);
   delete c;
 }
 
@@ -746,6 +748,40 @@ int32_t eg_place(eg_ctx* c, int32_t gen_type, int32_t year_index, const uint16_t
   EG_HIP(hipMemcpy(&cell, d_cell, sizeof(cell), hipMemcpyDeviceToHost));
   EG_HIP(hipMemcpy(&score, d_score, sizeof(score), hipMemcpyDeviceToHost));
   if (out_cell) *out_cell = cell;
+  if (out_score) *out_score = score;
+  return EG_OK;
+}
+
+int32_t eg_find_suitable_location(eg_ctx* c, int32_t year_index, int32_t gen_type, const double* gen_x, const double* gen_y,
+                                  int32_t n_generators, float size_penalty, double* out_x, double* out_y, int32_t* found, double* out_score) {
+  if (!c || gen_type < 0 || gen_type >= EG_N_TYPES || year_index < 0 || year_index >= EG_YEARS || n_generators < 0 ||
+      (n_generators > 0 && (!gen_x || !gen_y))) { set_error("eg_find_suitable_location: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  if (!c->d_place_cell) {
+    EG_HIP(hipMalloc((void**)&c->d_place_cells, sizeof(uint16_t) * EG_MAX_GENS));
+    EG_HIP(hipMalloc((void**)&c->d_place_cell, sizeof(int32_t)));
+    EG_HIP(hipMalloc((void**)&c->d_place_score, sizeof(double)));
+  }
+  if (n_generators > c->place_xy_cap) {
+    if (c->d_place_xy) (void)hipFree(c->d_place_xy);
+    c->d_place_xy = nullptr; c->place_xy_cap = 0;
+    EG_HIP(hipMalloc((void**)&c->d_place_xy, sizeof(double) * 2 * size_t(n_generators)));
+    c->place_xy_cap = n_generators;
+  }
+  if (n_generators) {
+    EG_HIP(hipMemcpy(c->d_place_xy, gen_x, sizeof(double) * n_generators, hipMemcpyHostToDevice));
+    EG_HIP(hipMemcpy(c->d_place_xy + c->place_xy_cap, gen_y, sizeof(double) * n_generators, hipMemcpyHostToDevice));
+  }
+  const double radius = class_radius(c->tables.H.rclass[gen_type]);
+  const double size_term = 1.0 - (double(size_penalty) * 0.1);                     // metal_location_search.rs:165
+  int lr = launch_place_xy(c->dev, gen_type, year_index, c->d_place_xy, c->d_place_xy + c->place_xy_cap, n_generators, radius, size_term,
+                           c->d_place_cell, c->d_place_score, nullptr);
+  if (lr != 0) { set_error(std::string("k_place_xy launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  int32_t cell = -1; double score = 0.0;
+  EG_HIP(hipMemcpy(&cell, c->d_place_cell, sizeof(cell), hipMemcpyDeviceToHost));
+  EG_HIP(hipMemcpy(&score, c->d_place_score, sizeof(score), hipMemcpyDeviceToHost));
+  if (found) *found = cell >= 0 ? 1 : 0;
+  if (cell >= 0) { if (out_x) *out_x = double(cell / EG_GRID) * 1000.0; if (out_y) *out_y = double(cell % EG_GRID) * 1000.0; }
   if (out_score) *out_score = score;
   return EG_OK;
 }

@@ -258,6 +258,9 @@ int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, l
                         const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
+int launch_place_xy(const DevTables& t, int gen_type, int year_index, const double* d_x, const double* d_y, int n, double radius,
+                    double size_term, int32_t* d_out_cell, double* d_out_score, void* stream);
+double class_radius(int radius_class);      // eg_tables.cpp: metal_location_search.rs:139-146
 // scalars of the contrast step that depend only on the snapshot (learning.rs:131-180); filled in the kernels from
 // snap::state
 struct StatsParams {

@@ -1830,6 +1830,38 @@ __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, 
   if (lane == 0) { *out_cell = cell; *out_score = score; }
 }
 
+// ---- B2 with the reference's own signature: generators at arbitrary coordinates, a size penalty --------------------
+// MetalLocationSearch::find_suitable_location (metal_location_search.rs:96-176) for the ctx's settlements (populations of
+// year `yi`) and existing plant — that part of every candidate's product is the host table te, in the reference's order —
+// times, for each of the caller's generators in list order, distance / radius when closer than the radius (sqrt and division
+// are IEEE correctly rounded here as in the reference), times the coast factor, times 1 - size_penalty * 0.1.  All 2601
+// distinct candidates are evaluated (no generator sits on the 1 km grid, so nothing of the rollout's tables applies);
+// first maximum in (i, j) order = highest score, ties to the lowest cell.
+__global__ void __launch_bounds__(kWave) k_place_xy(DevTables T, int type, int yi, const double* __restrict__ gx, const double* __restrict__ gy,
+                                                    int n, double radius, double size_term, int32_t* out_cell, double* out_score) {
+  const int lane = threadIdx.x;
+  const int rc = T.rclass()[type], v = T.variant()[type];
+  const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
+  (void)rc;
+  double best = 0.0; int best_c = kCells;
+  for (int r = lane; r < kCells; r += kWave) {
+    const PsRec c = list[r];
+    const int ci = (int)c.cell / kGrid, cj = (int)c.cell - ci * kGrid;
+    const double x = (double)ci * 1000.0, y = (double)cj * 1000.0;
+    double score = c.te;
+    for (int g = 0; g < n; ++g) {
+      const double dx = x - gx[g], dy = y - gy[g];
+      const double distance = __builtin_sqrt(dx * dx + dy * dy);
+      if (distance < radius) score = score * (distance / radius);
+    }
+    score = score * c.cf;            // 1.0 for the types without the coast term (x * 1.0 == x)
+    score = score * size_term;
+    if (score > best || (score == best && score > 0.0 && (int)c.cell < best_c)) { best = score; best_c = (int)c.cell; }
+  }
+  const ChunkBest b = chunk_reduce<false>(best, best_c, 0.0);
+  if (lane == 0) { *out_cell = b.score > 0.0 ? b.cell : -1; *out_score = b.score; }
+}
+
 // Stalled sampler tables of a freshly uploaded snapshot (sampling.rs:190-220 on the un-nudged rows): per year the
 // weights in stable descending order raised to the power (shared eg_detpow), the permutation and the table-order sum.
 // One workgroup per year; runs on the stream right behind the snapshot copy.
@@ -2212,6 +2244,12 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream) {
   hipLaunchKernelGGL(k_place, dim3(1), dim3(kWave), 0, (hipStream_t)stream, t, gen_type, year_index, d_cells, n_extra,
+                     d_out_cell, d_out_score);
+  return (int)hipGetLastError();
+}
+int launch_place_xy(const DevTables& t, int gen_type, int year_index, const double* d_x, const double* d_y, int n, double radius,
+                    double size_term, int32_t* d_out_cell, double* d_out_score, void* stream) {
+  hipLaunchKernelGGL(k_place_xy, dim3(1), dim3(kWave), 0, (hipStream_t)stream, t, gen_type, year_index, d_x, d_y, n, radius, size_term,
                      d_out_cell, d_out_score);
   return (int)hipGetLastError();
 }

@@ -120,6 +120,9 @@ double loader_max_power(int t) {  // generators_loader.rs:118-131
     case 8: return 400.0; case 10: return 1200.0; case 9: return 50.0; default: return 800.0;
   }
 }
+}  // namespace
+double class_radius(int radius_class) { return kClassRadius[radius_class]; }
+namespace {
 int rclass_of(double radius) {
   for (int k = 0; k < kRadiusClasses; ++k) if (kClassRadius[k] == radius) return k;
   return kRadiusClasses - 1;

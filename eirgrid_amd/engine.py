@@ -389,8 +389,19 @@ class Engine:
         """Test hook: leave `value` in every LDS word of every CU (LDS is not cleared between workgroups)."""
         N.check(N.lib().eg_debug_fill_lds(self.h, C.c_uint32(value & 0xFFFFFFFF)), "eg_debug_fill_lds")
 
+    def find_suitable_location_xy(self, gen_type: int, generators_xy=(), size_penalty: float = 1.0, year_index: int = 0):
+        """MetalLocationSearch::find_suitable_location with the reference's signature (gpu/metal_location_search.rs:96-103):
+        further generators at arbitrary coordinates, an f32 size penalty.  Returns ((x, y) or None, best score)."""
+        gx = np.ascontiguousarray([p[0] for p in generators_xy], dtype=np.float64)
+        gy = np.ascontiguousarray([p[1] for p in generators_xy], dtype=np.float64)
+        x, y, score, found = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        N.check(N.lib().eg_find_suitable_location(self.h, year_index, gen_type, _p(gx, C.c_double) if len(gx) else None,
+                                                  _p(gy, C.c_double) if len(gy) else None, len(gx), C.c_float(size_penalty),
+                                                  C.byref(x), C.byref(y), C.byref(found), C.byref(score)), "eg_find_suitable_location")
+        return ((x.value, y.value) if found.value else None), score.value
+
     def find_suitable_location(self, gen_type: int, year_index: int = 0, extra_cells=()):
-        """gpu/metal_location_search.rs:96-103 on the device: returns (cell or -1, best score)."""
+        """The same search as the rollout kernels run it (generators on the 1 km grid): returns (cell or -1, best score)."""
         cells = np.ascontiguousarray(list(extra_cells), dtype=np.uint16)
         cell, score = C.c_int32(), C.c_double()
         N.check(N.lib().eg_place(self.h, gen_type, year_index, _p(cells, C.c_uint16) if len(cells) else None, len(cells),

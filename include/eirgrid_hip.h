@@ -7,7 +7,8 @@
  *   eg_create / eg_destroy      Map::new + initialize_map              utils/map_handler.rs:351-399, main.rs:74-193
  *   eg_rollout_batch            run_iteration, batched over episodes   core/iteration.rs:10-20 (callers:
  *                                                                       core/multi_simulation.rs:472, :690)
- *   eg_place                    MetalLocationSearch::find_suitable_location   gpu/metal_location_search.rs:96-103
+ *   eg_find_suitable_location   MetalLocationSearch::find_suitable_location   gpu/metal_location_search.rs:96-103
+ *   eg_place                    the same search as the rollout kernels run it (generators on the 1 km grid), for parity tests
  *   eg_policy_*                 ActionWeights::{new, update_*, apply_*}        ai/learning/weights/ (all files)
  *   eg_policy_apply_episode     the write-locked section               core/multi_simulation.rs:494-508
  *   eg_train_step, eg_policy_push / eg_device_step / eg_policy_pull    the body of the training loop (one batch of
@@ -216,6 +217,15 @@ int32_t eg_debug_fill_lds(eg_ctx *, uint32_t value);
  * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */
 int32_t eg_place(eg_ctx *, int32_t gen_type, int32_t year_index, const uint16_t *extra_cells, int32_t n_extra,
                  int32_t *out_cell, double *out_score);
+
+/* B2 with the reference's own signature — MetalLocationSearch::find_suitable_location(&self, settlements, generators,
+ * coastline_points, gen_type, size_penalty: f32) -> Option<Coordinate> (gpu/metal_location_search.rs:96-103): the settlements
+ * (with the populations of year `year_index`), the existing plant and the coastline are the ctx's world; `gen_x / gen_y` are
+ * the further generators of the caller's map at ARBITRARY coordinates (metres), in list order.  *found = 0 is the
+ * reference's None; otherwise (*out_x, *out_y) is the winning candidate's coordinate as Coordinate::new clamps it. */
+int32_t eg_find_suitable_location(eg_ctx *, int32_t year_index, int32_t gen_type, const double *gen_x, const double *gen_y,
+                                  int32_t n_generators, float size_penalty, double *out_x, double *out_y, int32_t *found,
+                                  double *out_score /* may be NULL */);
 
 /* ---- policy-independent host tables (built once per world; no device needed), read-only views for validation.
  * Names: usage population pre_co2 pre_tg pre_ig pre_sg pre_optot te coastf dr m03 t12 cc out_mw co2_t offv offc

@@ -121,6 +121,8 @@ def lib():
     L.og_action_cost_estimate.argtypes = [C.c_int32, C.c_int32]
     L.og_place.restype = C.c_int32
     L.og_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp]
+    L.og_place_sized.restype = C.c_int32
+    L.og_place_sized.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, dp, dp, C.c_float, dp]
     L.og_chacha_block.argtypes = [u32p, C.c_uint64, C.c_uint64, C.c_int32, u32p]
     L.og_rng_seed_words.argtypes = [C.c_uint64, u32p]
     L.og_rng_stream.argtypes = [C.c_uint64, C.c_int32, u64p]
@@ -169,11 +171,11 @@ class OracleWorld:
     def existing_online(self):
         return [lib().og_world_existing_online(self.h, g) for g in range(self.n_existing)]
 
-    def place(self, yi, gen_type, extra_xy=()):
+    def place(self, yi, gen_type, extra_xy=(), size_penalty=1.0):
         ex = np.array([p[0] for p in extra_xy], dtype=np.float64)
         ey = np.array([p[1] for p in extra_xy], dtype=np.float64)
         score = C.c_double()
-        cell = lib().og_place(self.h, yi, gen_type, len(ex), _dp(ex), _dp(ey), C.byref(score))
+        cell = lib().og_place_sized(self.h, yi, gen_type, len(ex), _dp(ex), _dp(ey), C.c_float(size_penalty), C.byref(score))
         return cell, score.value
 
 

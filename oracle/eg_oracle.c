@@ -1483,14 +1483,16 @@ double og_action_cost_estimate(int32_t action, int32_t year) {
   return 0.0;
 }
 int32_t og_place(const og_world *w, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,
-                 double *best_score) {
+                 double *best_score) { return og_place_sized(w, yi, type, n_extra, ex, ey, 1.0f, best_score); }
+int32_t og_place_sized(const og_world *w, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,
+                       float size_penalty, double *best_score) {
   map_t m; map_init(&m, w);
   for (int k = 1; k <= yi; ++k)
     for (int s = 0; s < m.S; ++s) m.settle[s].pop = (uint32_t)round_half_away((double)m.settle[s].pop * 1.01);
   coord *extra = (coord *)malloc(sizeof(coord) * (size_t)(n_extra > 0 ? n_extra : 1));
   for (int i = 0; i < n_extra; ++i) extra[i] = coord_new(ex[i], ey[i]);
   coord loc; double score = 0.0;
-  int found = find_suitable_location(m.settle, m.S, m.gens, m.ngens, extra, n_extra, w->coast, w->P, type, 1.0f, &loc, &score);
+  int found = find_suitable_location(m.settle, m.S, m.gens, m.ngens, extra, n_extra, w->coast, w->P, type, size_penalty, &loc, &score);
   if (best_score) *best_score = score;
   free(extra); map_free(&m);
   return found ? cell_of(loc) : -1;

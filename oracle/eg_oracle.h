@@ -158,6 +158,9 @@ double og_action_cost_estimate(int32_t action, int32_t year);                   
  * explicit extra generators; returns canonical cell or -1 */
 int32_t og_place(const og_world *, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,
                  double *best_score);
+/* ... with the reference's size_penalty: f32 argument (metal_location_search.rs:102, :165); og_place passes 1.0 */
+int32_t og_place_sized(const og_world *, int32_t yi, int32_t type, int32_t n_extra, const double *ex, const double *ey,
+                       float size_penalty, double *best_score);
 
 /* ---- rand 0.8.5 StdRng = ChaCha12 (Cargo.lock:763-785) ---- */
 void og_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int32_t rounds, uint32_t out[16]);

@@ -464,3 +464,30 @@ def test_heavy_episodes_match_the_oracle(world):
     # the field path really ran: the same episodes take a fraction of the exact scan's time
     print("k_rollout ms for the four batches:", {f"{k[0]}/{k[1]}": round(v, 2) for k, v in kernel_ms.items()})
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
+
+
+def test_find_suitable_location_with_the_reference_signature(engine, oracle_world):
+    """B2 as the reference declares it (metal_location_search.rs:96-103): generators at arbitrary coordinates (off the 1 km
+    grid, on it, on top of candidates, outside every radius) and an f32 size penalty — cell AND score bit-identical to the
+    literal 100 x 100 search of the oracle, for all 15 types, several years, 0 to 300 generators."""
+    rng = np.random.default_rng(5)
+    checked = 0
+    for trial in range(24):
+        n = int(rng.choice([0, 1, 3, 17, 80, 300]))
+        xy = np.column_stack([rng.uniform(0.0, 50000.0, n), rng.uniform(0.0, 50000.0, n)])
+        if n >= 3:
+            xy[0] = (12000.0, 31000.0)                 # exactly on a candidate: its score becomes 0
+            xy[1] = np.round(xy[1] / 1000.0) * 1000.0   # on the grid
+            xy[2] = (49999.999, 0.001)
+        for t in range(15):
+            yi = int(rng.integers(0, 26)); sp = float(rng.choice([1.0, 0.0, 0.35, 2.5]))
+            got_xy, got_score = engine.find_suitable_location_xy(t, [tuple(p) for p in xy], size_penalty=sp, year_index=yi)
+            cell, score = oracle_world.place(yi, t, [tuple(p) for p in xy], size_penalty=sp)
+            assert np.float64(got_score).tobytes() == np.float64(score).tobytes(), (trial, t, yi, n, got_score, score)
+            assert (got_xy is None) == (cell < 0)
+            if cell >= 0:
+                assert got_xy == (float(cell // 51) * 1000.0, float(cell % 51) * 1000.0), (trial, t)
+            checked += 1
+    assert checked == 24 * 15
+    # a size penalty of 10 makes every score 0: None, as in the reference
+    assert engine.find_suitable_location_xy(0, [], size_penalty=10.0)[0] is None
