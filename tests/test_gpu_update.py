@@ -164,7 +164,7 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
     assert line["config"]["last_batch"]["ok"] == 256 and line["config"]["episodes_failed"] == 0
-    assert line["roofline"]["frac"] <= 1.0 and line["roofline"]["touched_bytes_per_launch"] < line["roofline"]["nominal_bytes_per_launch"]
+    assert 0.0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["touched_bytes_per_launch"] > 0
 
 
 def test_train_step_equals_the_stepwise_path(engine):
