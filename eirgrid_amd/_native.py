@@ -64,7 +64,7 @@ EXPORTS = [
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
     "eg_policy_get_scalar", "eg_policy_set_scalar", "eg_policy_get_list", "eg_policy_apply_episode", "eg_score_metrics",
-    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history", "eg_policy_export_improvement_csv", "eg_export_summary_csv",
+    "eg_policy_save_json", "eg_policy_load_json", "eg_policy_append_weight_history", "eg_policy_export_improvement_csv", "eg_export_summary_csv", "eg_export_run_details",
 ]
 
 _lib = None
@@ -149,6 +149,8 @@ def lib():
     L.eg_policy_export_improvement_csv.restype = C.c_int32
     L.eg_export_summary_csv.restype = C.c_int32
     L.eg_export_summary_csv.argtypes = [C.POINTER(EgEpisodeOut), C.c_char_p, C.c_char_p]
+    L.eg_export_run_details.restype = C.c_int32
+    L.eg_export_run_details.argtypes = [C.POINTER(EgWorld), C.POINTER(C.c_char_p), C.POINTER(EgEpisodeOut), C.c_char_p, C.c_uint64]
     L.eg_fetch_record.restype = C.c_int32
     L.eg_fetch_record.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(EgEpisodeOut)]
     L.eg_fetch_best_run.restype = C.c_int32

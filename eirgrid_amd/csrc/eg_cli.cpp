@@ -7,8 +7,9 @@
 // absent, :38-39, :437-465).  Iterations run on the GPU in batches that share one weights snapshot — the GPU
 // counterpart of rayon workers cloning the shared weights (:457-460) — and are folded into the weights either one by
 // one in index order (--update sequential: multi_simulation.rs:494-508 verbatim) or with the batch form
-// (--update reduced, default).  Of the best-run CSV export (--enable-csv-export, N3) simulation_summary.csv and
-// improvement_history.csv are written; the per-settlement / per-generator detail files are not.
+// (--update reduced, default).  The best-run CSV export (--enable-csv-export, N3) writes what the
+// reference's exporter writes: simulation_summary.csv, improvement_history.csv, yearly_details/{settlements,generators,
+// carbon_offsets}.csv and operation_logs/generator_operation_logs.csv (csrc/eg_export.cpp describes their contents).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -107,6 +108,7 @@ void mkdirs(const std::string& p) { std::string cur; for (size_t i = 0; i <= p.s
 
 struct WorldData {
   std::vector<double> sx, sy; std::vector<uint32_t> spop; std::vector<double> gx, gy, gcap; std::vector<int32_t> gtype; std::vector<double> cx, cy;
+  std::vector<std::string> names;      // settlement names (settlements.csv of the export); empty: "Settlement_<i>"
   eg_world view(bool at_start) const {
     eg_world w{}; w.n_settlements = int32_t(sx.size()); w.settlement_x = sx.data(); w.settlement_y = sy.data(); w.settlement_pop = spop.data();
     w.n_existing = int32_t(gx.size()); w.existing_x = gx.data(); w.existing_y = gy.data(); w.existing_type = gtype.data(); w.existing_capacity_mw = gcap.data();
@@ -128,6 +130,8 @@ bool load_world_json(const std::string& path, WorldData& w) {   // eirgrid_amd.w
   nums(r.get("coast_x"), w.cx); nums(r.get("coast_y"), w.cy);
   for (double p : pop) w.spop.push_back(uint32_t(p));
   for (double t : type) w.gtype.push_back(int32_t(t));
+  if (const eg::Json* nm = r.get("settlement_names"); nm && nm->kind == eg::Json::Arr && nm->arr.size() == w.sx.size())
+    for (auto& v : nm->arr) w.names.push_back(v.str);
   return !w.sx.empty() && w.sx.size() == w.sy.size() && w.sx.size() == w.spop.size() && w.gx.size() == w.gtype.size();
 }
 // const_funcs.rs:124-136 + constants.rs:131-134, :270-271
@@ -145,7 +149,10 @@ bool load_reference_assets(const std::string& dir, WorldData& w) {   // main.rs:
   for (auto& e : list->arr) {   // data/settlements_loader.rs:23-41
     const eg::Json *lat = e.get("lat"), *lon = e.get("lon"), *pop = e.get("population");
     double x, y;
-    if (lat && lon && pop && lat_lon_to_grid(lat->num, lon->num, x, y)) { w.sx.push_back(x); w.sy.push_back(y); w.spop.push_back(uint32_t(pop->num)); }
+    if (lat && lon && pop && lat_lon_to_grid(lat->num, lon->num, x, y)) {
+      w.sx.push_back(x); w.sy.push_back(y); w.spop.push_back(uint32_t(pop->num));
+      const eg::Json* name = e.get("name"); w.names.push_back(name ? name->str : "Settlement_" + std::to_string(w.names.size()));
+    }
   }
   std::string csv;
   if (!read_file(dir + "/ireland_generators.csv", csv)) return false;
@@ -195,7 +202,6 @@ int main(int argc, char** argv) {
   if (!parse(argc, argv, a)) return 2;
   std::puts("EirGrid Power System Simulator (2025-2050) — MI355X rollout engine");
   if (a.enable_construction_delays) { std::fprintf(stderr, "error: --enable-construction-delays is not implemented on the device (DESIGN.md §6)\n"); return 2; }
-  if (a.enable_csv_export) std::puts("note: the best-run CSV export (N3) writes enhanced_csv/<timestamp>/{simulation_summary,improvement_history}.csv; the yearly_details/ and operation_logs/ files are not written");
 
   WorldData wd;
   if (!a.world_json.empty()) { if (!load_world_json(a.world_json, wd)) { std::fprintf(stderr, "error: cannot read world %s\n", a.world_json.c_str()); return 1; } }
@@ -234,8 +240,10 @@ int main(int argc, char** argv) {
   struct BestRun {
     std::vector<double> metrics = std::vector<double>(4), yearly = std::vector<double>(size_t(EG_YEARS) * EG_YEARLY_FIELDS);
     std::vector<int32_t> n_act = std::vector<int32_t>(EG_YEARS); std::vector<uint8_t> act_log = std::vector<uint8_t>(EG_ACT_CAP);
+    std::vector<uint16_t> gen_pack = std::vector<uint16_t>(EG_MAX_GENS); int32_t n_gens = 0;
     eg_episode_out view{}; bool valid = false;
-    BestRun() { view.metrics = metrics.data(); view.yearly = yearly.data(); view.n_act = n_act.data(); view.act_log = act_log.data(); }
+    BestRun() { view.metrics = metrics.data(); view.yearly = yearly.data(); view.n_act = n_act.data(); view.act_log = act_log.data();
+                view.n_gens = &n_gens; view.gen_pack = gen_pack.data(); }
   } best_run;
   std::vector<uint8_t> mask;
   std::vector<double> metrics; std::vector<int32_t> n_run, n_def; std::vector<uint8_t> run_log, def_log;
@@ -321,8 +329,12 @@ int main(int argc, char** argv) {
     mkdirs(dir);
     CHECK(eg_policy_export_improvement_csv(policy, (dir + "/improvement_history.csv").c_str()));
     if (reduced) { int32_t state = 0; CHECK(eg_fetch_best_run(ctx, &best_run.view, &state)); best_run.valid = state == 1; }
-    if (best_run.valid) CHECK(eg_export_summary_csv(&best_run.view, (dir + "/simulation_summary.csv").c_str(), stamp));
-    else std::puts("note: no improvement in this run; simulation_summary.csv not written");
+    if (best_run.valid) {
+      CHECK(eg_export_summary_csv(&best_run.view, (dir + "/simulation_summary.csv").c_str(), stamp));
+      std::vector<const char*> names;
+      for (const std::string& n : wd.names) names.push_back(n.c_str());
+      CHECK(eg_export_run_details(&world, names.size() == wd.sx.size() ? names.data() : nullptr, &best_run.view, dir.c_str(), a.seed));
+    } else std::puts("note: no improvement in this run; simulation_summary.csv and the detail files not written");
   }
   std::printf("Done: %llu iterations in %s (%u episodes failed); best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
               (unsigned long long)done, run_dir.c_str(), unsigned(eg_policy_get_scalar(policy, 13)) + failed_sequential);

@@ -211,6 +211,20 @@ class BatchResult:
         out = one.struct()
         N.check(N.lib().eg_export_summary_csv(C.byref(out), path.encode(), timestamp.encode()), "eg_export_summary_csv")
 
+    def export_run_details(self, world: World, out_dir: str, settlement_names=None, offset_seed: int = 0, episode: int = 0) -> None:
+        """yearly_details/{settlements,generators,carbon_offsets}.csv + operation_logs/generator_operation_logs.csv of one
+        episode of this result (utils/csv_export.rs:434-1230; eg_export_run_details)."""
+        one = BatchResult(*[np.ascontiguousarray(getattr(self, f)[episode:episode + 1]) for f in
+                            ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "run_log", "def_log", "act_log", "n_gens",
+                             "gen_cell", "gen_pack", "n_offsets", "off_pack", "n_draws", "bytes_moved", "n_chunks")])
+        out = one.struct()
+        w, keep = _world_struct(world)
+        names = None
+        if settlement_names is not None:
+            names = (C.c_char_p * len(settlement_names))(*[n.encode() for n in settlement_names])
+        N.check(N.lib().eg_export_run_details(C.byref(w), names, C.byref(out), str(out_dir).encode(), C.c_uint64(offset_seed & (2**64 - 1))),
+                "eg_export_run_details")
+
     def bytes_touched(self) -> np.ndarray:
         """Per episode: the SURVEY §8(d) bytes with the score field of every search (2601 x 8 B, never read by the
         branch-and-bound search) replaced by the candidate records the search requested (n_chunks x 64 x 32 B)."""

@@ -295,6 +295,14 @@ int32_t eg_policy_export_improvement_csv(const eg_policy *, const char *path);  
 /* simulation_summary.csv of the best-run export (utils/csv_export.rs:215-432): final metrics, the action list with the
  * exporter's cost estimates, the yearly summary rows.  `run` holds one episode (metrics, yearly, n_act, act_log). */
 int32_t eg_export_summary_csv(const eg_episode_out *run, const char *path, const char *timestamp);
+/* The detail files of the same export (utils/csv_export.rs:434-1230, called from core/multi_simulation.rs:852-905):
+ * <out_dir>/yearly_details/{settlements,generators,carbon_offsets}.csv and <out_dir>/operation_logs/generator_operation_logs.csv,
+ * from the best episode's record (`run`: n_gens, gen_pack, n_act, act_log are read) and the world.  Host code, no device.
+ * settlement_names: [n_settlements] or NULL ("Settlement_<i>").  offset_seed: carbon-offset coordinates come from thread_rng in
+ * the reference (core/actions.rs:142-145); here from StdRng::seed_from_u64(offset_seed).  What the reference really writes —
+ * and therefore this function — is described at the top of csrc/eg_export.cpp. */
+int32_t eg_export_run_details(const eg_world *world, const char *const *settlement_names, const eg_episode_out *run,
+                              const char *out_dir, uint64_t offset_seed);
 double eg_score_metrics(const double metrics[4], int32_t cost_only);   /* ai/metrics/scoring.rs:5-45 */
 
 #ifdef __cplusplus

@@ -67,3 +67,224 @@ def summary_csv_text(metrics, yearly, n_act, act_log, timestamp: str) -> str:
                      f"{r[Y_NET_CO2]:.2f},{r[Y_YEARLY_CREDIT]:.2f},{r[Y_TOTAL_CREDIT]:.2f},{int(r[Y_ACTIVE_GENS])},"
                      f"{r[Y_UPGRADE_COSTS]:.2f},{r[Y_CLOSURE_COSTS]:.2f},{r[Y_YEARLY_TOTAL_COST]:.2f},{r[Y_TOTAL_COST]:.2f}")
     return "\n".join(lines) + "\n"
+
+
+# ============================================================================================================
+# The detail files of the export (utils/csv_export.rs:434-1230), restated literally: a "final map" object model, the
+# exporter's two passes over it, the id-string parsing.  Checker of eg_export_run_details (csrc/eg_export.cpp).
+# ============================================================================================================
+import math
+
+LIFESPAN = [25, 25, 25, 25, 30, 60, 40, 30, 25, 25, 100, 80, 15, 25, 20]            # models/generator.rs:344-362
+MAP_MAX = 50000.0                                                                   # config/constants.rs:6-7
+BASE_YEAR, END_YEAR = 2025, 2050
+
+
+def powi(a: float, b: int) -> float:
+    """Rust f64::powi = compiler-rt __powidf2 (repeated squaring, this exact order of multiplications)."""
+    recip, r = b < 0, 1.0
+    while True:
+        if b & 1:
+            r *= a
+        b = int(b / 2)
+        if b == 0:
+            break
+        a *= a
+    return 1.0 / r if recip else r
+
+
+def grid_to_lon_lat(x: float, y: float):
+    """csv_export.rs:42-84"""
+    xv, yv = min(max(x, 0.0), MAP_MAX), min(max(y, 0.0), MAP_MAX)
+    return -10.6 + ((-5.9 - -10.6) * (xv / MAP_MAX)), 51.4 + ((55.4 - 51.4) * (yv / MAP_MAX))
+
+
+def sanitize_id(s: str) -> str:
+    return "".join(c for c in s if c.isalnum() or c.isspace() or c == "_")          # csv_export.rs:565-569
+
+
+def extract_generator_type(gid: str) -> str:
+    """csv_export.rs:604-647, in the source's order of tests"""
+    for needles, name in ((("Onshore", "OnshoreWind"), "OnshoreWind"), (("Offshore", "OffshoreWind"), "OffshoreWind"),
+                          (("DomesticSolar",), "DomesticSolar"), (("CommercialSolar",), "CommercialSolar"), (("UtilitySolar",), "UtilitySolar"),
+                          (("Nuclear",), "Nuclear"), (("Coal", "CoalPlant"), "CoalPlant"), (("GasCombinedCycle",), "GasCombinedCycle"),
+                          (("GasPeaker",), "GasPeaker"), (("Biomass",), "Biomass"), (("Hydro", "HydroDam"), "HydroDam"),
+                          (("PumpedStorage",), "PumpedStorage"), (("Battery", "BatteryStorage"), "BatteryStorage"),
+                          (("Tidal", "TidalGenerator"), "TidalGenerator"), (("Wave", "WaveEnergy"), "WaveEnergy")):
+        if any(n in gid for n in needles):
+            return name
+    parts = gid.split("_")
+    return parts[1] if len(parts) >= 2 else "Unknown"
+
+
+def parse_u32(s: str):
+    body = s[1:] if s.startswith("+") else s
+    if not body or not all("0" <= c <= "9" for c in body) or int(body) > 0xFFFFFFFF:
+        return None
+    return int(body)
+
+
+def extract_commissioning_year(gid: str, default_year: int) -> int:
+    parts = gid.split("_")                                                           # csv_export.rs:650-658
+    if len(parts) >= 3:
+        v = parse_u32(parts[2])
+        return default_year if v is None else v
+    return default_year
+
+
+DEFAULT_POWER = {"OnshoreWind": 50.0, "OffshoreWind": 200.0, "DomesticSolar": 0.01, "CommercialSolar": 0.5, "UtilitySolar": 50.0,
+                 "Nuclear": 1000.0, "CoalPlant": 500.0, "GasCombinedCycle": 400.0, "GasPeaker": 100.0, "Biomass": 50.0, "HydroDam": 250.0,
+                 "PumpedStorage": 200.0, "BatteryStorage": 50.0, "TidalGenerator": 30.0, "WaveEnergy": 20.0}      # :661-680
+CO2_PER_MW = {"CoalPlant": 3.0, "GasCombinedCycle": 0.4, "GasPeaker": 0.5, "Biomass": 0.1}                        # :683-695
+ZERO_CO2 = {"OnshoreWind", "OffshoreWind", "DomesticSolar", "CommercialSolar", "UtilitySolar", "HydroDam", "PumpedStorage",
+            "BatteryStorage", "TidalGenerator", "WaveEnergy", "Nuclear"}
+RELIABILITY = {"OnshoreWind": 0.35, "OffshoreWind": 0.35, "DomesticSolar": 0.25, "CommercialSolar": 0.25, "UtilitySolar": 0.25, "Nuclear": 0.95,
+               "CoalPlant": 0.90, "GasCombinedCycle": 0.85, "GasPeaker": 0.90, "Biomass": 0.80, "HydroDam": 0.75, "PumpedStorage": 0.95,
+               "BatteryStorage": 0.98, "TidalGenerator": 0.45, "WaveEnergy": 0.40}                               # :873-888
+CAPITAL_PER_MW = {"OnshoreWind": 1_500_000.0, "OffshoreWind": 3_500_000.0, "DomesticSolar": 1_000_000.0, "CommercialSolar": 800_000.0,
+                  "UtilitySolar": 600_000.0, "Nuclear": 6_000_000.0, "CoalPlant": 2_000_000.0, "GasCombinedCycle": 1_000_000.0,
+                  "GasPeaker": 500_000.0, "Biomass": 3_000_000.0, "HydroDam": 2_500_000.0, "PumpedStorage": 2_000_000.0,
+                  "BatteryStorage": 400_000.0, "TidalGenerator": 5_000_000.0, "WaveEnergy": 4_000_000.0}          # :923-940
+TECH = {"OnshoreWind": "OnshoreWind", "OffshoreWind": "OffshoreWind", "DomesticSolar": "SolarPV", "CommercialSolar": "SolarPV",
+        "UtilitySolar": "SolarPV", "GasCombinedCycle": "Gas", "GasPeaker": "Gas", "CoalPlant": "Coal", "Nuclear": "Nuclear", "HydroDam": "Hydro",
+        "PumpedStorage": "Storage", "BatteryStorage": "Storage", "Biomass": "Biomass", "TidalGenerator": "Tidal", "WaveEnergy": "Wave"}   # tech_type.rs:53-67
+PLANNING = {"OnshoreWind": (1.5, 0.5), "OffshoreWind": (3.0, 1.0), "SolarPV": (1.0, 0.3), "Gas": (2.0, 1.0), "Coal": (2.0, 1.0),
+            "Nuclear": (5.0, 3.0), "Hydro": (2.5, 1.5), "Storage": (1.5, 0.8), "Biomass": (2.0, 1.0), "Tidal": (3.0, 1.5), "Wave": (3.0, 1.5)}
+CONSTRUCTION = {"OnshoreWind": (1.25, 0.75), "OffshoreWind": (3.0, 2.0), "SolarPV": (0.5, 0.25), "Gas": (2.5, 2.0), "Coal": (3.0, 3.0),
+                "Nuclear": (7.0, 4.0), "Hydro": (4.0, 3.5), "Storage": (1.0, 0.5), "Biomass": (2.0, 1.5), "Tidal": (2.0, 1.5), "Wave": (2.0, 1.5)}
+
+
+def _duration(table, year: int, tech: str) -> float:
+    base, best = table[tech]                                                         # tech_type.rs:70-200
+    t = (float(min(max(year, BASE_YEAR), 2050)) - float(BASE_YEAR)) / (2050.0 - float(BASE_YEAR))
+    return max(base + t * (best - base), best)
+
+
+def detail_files(world, settlement_names, existing_online, gen_types, gen_years, n_act, act_log, offset_seed: int):
+    """The four files as {relative path: text}.
+    world: eirgrid_amd.world.World; existing_online: year index at which each existing generator becomes active in the simulated
+    episode (oracle: og_world_existing_online); gen_types / gen_years: the episode's added generators in order (type index, year
+    index); n_act / act_log: SimulationResult.actions; offset_seed: stands in for thread_rng (core/actions.rs:142-145)."""
+    S, G0 = len(world.settlement_x), len(world.existing_x)
+    names = list(settlement_names) if settlement_names is not None else [f"Settlement_{i}" for i in range(S)]
+    files = {}
+
+    # ---- settlements.csv (:457-533)
+    rows = ["Year,Name,Longitude,Latitude,Population,PowerUsage"]
+    for year in range(BASE_YEAR, END_YEAR + 1):
+        k = year - BASE_YEAR
+        for s in range(S):
+            lon, lat = grid_to_lon_lat(float(world.settlement_x[s]), float(world.settlement_y[s]))
+            base_population = int(world.settlement_pop[s])
+            base_power_usage = float(base_population) * (0.001 * math.pow(1.0 + 0.02, 0.0))       # settlements_loader.rs:29 with base_year 2025
+            population = int(math.floor(float(base_population) * powi(1.01, k) + 0.5))           # f64::round (positive values)
+            rows.append(f"{year},{names[s]},{lon:.6f},{lat:.6f},{population},{display_f64(base_power_usage * powi(1.02, k))}")
+    files["yearly_details/settlements.csv"] = "\n".join(rows) + "\n"
+
+    # ---- the simulated episode's map, for YearlyMetrics.generator_efficiencies / generator_operations (metrics_calculation.rs:90-103)
+    sim_ids = [f"Existing_{GENERATOR_TYPES[int(world.existing_type[g])]}_{g}" for g in range(G0)]
+    sim_first = [int(existing_online[g]) for g in range(G0)]
+    for k, (t, yi) in enumerate(zip(gen_types, gen_years)):
+        sim_ids.append(f"Gen_{GENERATOR_TYPES[int(t)]}_{BASE_YEAR + int(yi)}_{G0 + k}")             # actions.rs:60
+        sim_first.append(int(yi))
+    efficiencies = {y: [(i, 0.99) for i, f in zip(sim_ids, sim_first) if y - BASE_YEAR >= f] for y in range(BASE_YEAR, END_YEAR + 1)}
+    operations = {y: {i: float(int(1.0 * 100.0)) for i, f in zip(sim_ids, sim_first) if y - BASE_YEAR >= f} for y in range(BASE_YEAR, END_YEAR + 1)}
+
+    # ---- the final map (multi_simulation.rs:861-890): base map + the sampled actions re-applied, clock still at 2024
+    final_gens = [dict(id=sim_ids[g], type=int(world.existing_type[g]), x=float(world.existing_x[g]), y=float(world.existing_y[g]),
+                       commissioning_year=2024, eol=LIFESPAN[int(world.existing_type[g])], active=False) for g in range(G0)]
+    final_offsets = []
+    u64 = O.rng_stream(offset_seed, 2 * 1024)
+    draws = iter((v >> 11) * (1.0 / 9007199254740992.0) for v in u64)
+    pos = 0
+    for yi in range(26):
+        for _ in range(int(n_act[yi])):
+            a = int(act_log[pos]); pos += 1
+            if a < 45:      # AddGenerator: placed somewhere on the final map, "Planned", never active (the placement itself shows up in no file)
+                final_gens.append(dict(id=f"Gen_{GENERATOR_TYPES[a // 3]}_{BASE_YEAR + yi}_{len(final_gens)}", type=a // 3, x=None, y=None,
+                                       commissioning_year=2024, eol=LIFESPAN[a // 3], active=False))
+            elif a < 57:
+                ot, m = (a - 45) // 3, (a - 45) % 3
+                x = next(draws) * MAP_MAX; y = next(draws) * MAP_MAX
+                final_offsets.append(dict(id=f"Offset_{OFFSET_TYPES[ot]}_{BASE_YEAR + yi}_{len(final_offsets)}", type=ot, x=x, y=y,
+                                          mult=min(max([100, 120, 150][m] / 100.0, 1.0), 5.0), status="Planned"))
+
+    # ---- generators.csv (:535-985)
+    rows = ["Year,Generator ID,Type,Longitude,Latitude,Power Output (MW),Efficiency (%),Operation (%),CO2 Output (tonnes),Is Active,"
+            "Commissioning Year,End of Life Year,Size,Capital Cost (€),Operating Cost (€),Total Annual Cost (€),Reliability Factor,"
+            "Planning Time (years),Construction Time (years),Construction Speed"]
+    if not final_gens:
+        rows.append("NOTE,No generators found in the simulation")
+    else:
+        for year in range(BASE_YEAR, END_YEAR + 1):
+            processed = set()
+            for g in final_gens:                                                     # first pass (:698-805)
+                eol = min(g["eol"], END_YEAR)
+                if year < g["commissioning_year"] or year > eol:
+                    continue                                                         # eol is a lifespan: always taken
+                raise AssertionError("first-pass row: not restated (unreachable with the reference's lifespans)")
+            for gid, efficiency in efficiencies[year]:                               # second pass (:807-981), canonical order = map order
+                if gid in processed:
+                    continue
+                coords = None
+                if gid.startswith("Existing_"):
+                    for g in final_gens:
+                        if g["id"] == gid:
+                            coords = (g["x"], g["y"]); break
+                gen_type = extract_generator_type(gid)
+                commissioning_year = extract_commissioning_year(gid, BASE_YEAR)
+                eol_year = commissioning_year + 25
+                operation = operations[year].get(gid, 0.8) * 100.0
+                power_output = DEFAULT_POWER.get(gen_type, 100.0)
+                if gen_type in ZERO_CO2:
+                    co2_output = 0.0
+                else:
+                    co2_output = power_output * CO2_PER_MW.get(gen_type, 0.3) * 8760.0 / 1000.0
+                if coords is None:
+                    id_hash = sum(ord(c) for c in gid) & 0xFFFFFFFF
+                    coords = (5000.0 + float(id_hash % 100) / 100.0 * (MAP_MAX - 10000.0), 5000.0 + float((id_hash // 100) % 100) / 100.0 * (MAP_MAX - 10000.0))
+                lon, lat = grid_to_lon_lat(*coords)
+                reliability = RELIABILITY.get(gen_type, 0.75)
+                size = {"OnshoreWind": power_output / 3.0, "OffshoreWind": power_output / 8.0, "DomesticSolar": power_output * 8.0,
+                        "CommercialSolar": power_output * 6.0, "UtilitySolar": power_output * 2.0}.get(gen_type, power_output / 50.0)
+                capital_cost = power_output * CAPITAL_PER_MW.get(gen_type, 2_000_000.0)
+                operating_cost = capital_cost * 0.03
+                parsed = gen_type if gen_type in GENERATOR_TYPES else "GasCombinedCycle"          # GeneratorType::from_str, default :948-952
+                tech = TECH[parsed]
+                rows.append(f"{year},{sanitize_id(gid)},{parsed},{lon:.6f},{lat:.6f},{power_output:.2f},{efficiency * 100.0:.2f},{operation:.2f},"
+                            f"{co2_output:.2f},true,{commissioning_year},{eol_year},{size * 100.0:.2f},{capital_cost:.2f},{operating_cost:.2f},"
+                            f"{capital_cost + operating_cost:.2f},{reliability:.2f},{_duration(PLANNING, commissioning_year, tech):.2f},"
+                            f"{_duration(CONSTRUCTION, commissioning_year, tech):.2f},Normal")
+                processed.add(gid)
+    files["yearly_details/generators.csv"] = "\n".join(rows) + "\n"
+
+    # ---- carbon_offsets.csv (:987-1092)
+    rows = ["Year,Offset ID,Type,X,Y,Size,Capture Efficiency (%),Power Consumption (MW),CO2 Offset (tonnes),Negative CO2 Emissions (tonnes),"
+            "Cost (€),Operating Cost (€),Total Annual Cost (€),Cost Per Tonne (€)"]
+    SIZE, BASE_COST, OPERATING, FACTOR = [500.0, 300.0, 100.0, 1000.0], [1e6, 1e6, 1e9, 5e7], [10_000.0, 15_000.0, 100_000.0, 5_000.0], [1.0, 1.01, 0.97, 1.02]
+    for year in range(BASE_YEAR, END_YEAR + 1):
+        for o in final_offsets:
+            numeric = [v for v in (parse_u32(p) for p in o["id"].split("_")) if v is not None and BASE_YEAR <= v <= END_YEAR]
+            creation_year = numeric[0] if (len(o["id"].split("_")) >= 3 and numeric) else BASE_YEAR
+            if year < creation_year:
+                continue
+            lon, lat = grid_to_lon_lat(o["x"], o["y"])
+            co2_offset = 0.0 if o["status"] not in ("Operational", "UnderConstruction") else None      # carbon_offset.rs:209-260: Planned -> 0
+            cost = (BASE_COST[o["type"]] * powi(1.0 + 0.0185, year - BASE_YEAR)) * o["mult"]            # :186-193
+            operating = OPERATING[o["type"]] * powi(1.0 + 0.0185, year - BASE_YEAR) * math.pow(FACTOR[o["type"]], float(year - 2025))   # :195-207
+            total = cost + operating
+            per_tonne = total / co2_offset if co2_offset > 0.0 else 0.0
+            power = SIZE[o["type"]] * 0.5 if o["type"] == 2 else 0.0
+            rows.append(f"{year},{sanitize_id(o['id'])},{OFFSET_TYPES[o['type']]},{lon:.6f},{lat:.6f},{display_f64(SIZE[o['type']])},{0.85 * 100.0:.2f},"
+                        f"{display_f64(power)},{co2_offset:.2f},{-co2_offset:.2f},{cost:.2f},{operating:.2f},{total:.2f},{per_tonne:.2f}")
+    files["yearly_details/carbon_offsets.csv"] = "\n".join(rows) + "\n"
+
+    # ---- generator_operation_logs.csv (:1094-1230)
+    rows = ["Year,Month,Day,Hour,Generator ID,Type,Power Output (MW),Operation %,Actual Output (MW),Weather Factor,CO2 Emissions (tonnes)"]
+    for g in final_gens:
+        for year in range(g["commissioning_year"], min(g["eol"], END_YEAR) + 1):      # empty: eol is a lifespan
+            if not g["active"]:
+                continue
+            raise AssertionError("operation-log row: not restated (unreachable with the reference's lifespans)")
+    files["operation_logs/generator_operation_logs.csv"] = "\n".join(rows) + "\n"
+    return files

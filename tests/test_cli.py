@@ -63,7 +63,36 @@ def test_training_run_checkpoints_and_resume(built, tmp_path):
     exports = os.listdir(os.path.join(rd, "enhanced_csv"))
     assert len(exports) == 1 and re.fullmatch(r"\d{8}_\d{6}", exports[0])
     ed = os.path.join(rd, "enhanced_csv", exports[0])
-    assert {"improvement_history.csv", "simulation_summary.csv"} <= set(os.listdir(ed))
+    assert {"improvement_history.csv", "simulation_summary.csv", "yearly_details", "operation_logs"} <= set(os.listdir(ed))
+    assert set(os.listdir(os.path.join(ed, "yearly_details"))) == {"settlements.csv", "generators.csv", "carbon_offsets.csv"}
+    # the detail files against the literal restatement, rebuilt from the summary's own action list (sampled actions) and
+    # the generators.csv ids (the episode's generator list): every file byte for byte
+    from eirgrid_amd import synthetic_world
+    from oracle import api as O, csv_export as OC
+    world = synthetic_world()
+    gens = open(os.path.join(ed, "yearly_details", "generators.csv"), encoding="utf-8").read().split("\n")
+    added = []
+    for line in gens[1:]:
+        gid = line.split(",")[1] if line else ""
+        if gid.startswith("Gen_") and gid not in [g[0] for g in added]:
+            _, t, y, k = gid.split("_")
+            added.append((gid, OC.GENERATOR_TYPES.index(t), int(y) - 2025, int(k)))
+    added.sort(key=lambda g: g[3])
+    assert [g[3] for g in added] == list(range(59, 59 + len(added)))
+    summary_lines = open(os.path.join(ed, "simulation_summary.csv"), encoding="utf-8").read().split("\n")
+    i0 = summary_lines.index("Actions Taken") + 2
+    n_act = [0] * 26; act_log = []
+    for line in summary_lines[i0:summary_lines.index("Yearly Summary Metrics") - 1]:
+        year, kind, gen, _, _, off, _ = line.split(",")
+        a = {"AddGenerator": lambda: 3 * OC.GENERATOR_TYPES.index(gen), "AddCarbonOffset": lambda: 45 + 3 * OC.OFFSET_TYPES.index(off),
+             "UpgradeEfficiency": lambda: 57, "AdjustOperation": lambda: 58, "CloseGenerator": lambda: 59, "DoNothing": lambda: 60}[kind]()
+        n_act[int(year) - 2025] += 1; act_log.append(a)      # (the multiplier is not in the summary: offsets are re-priced below)
+    want = OC.detail_files(world, None, O.OracleWorld(world).existing_online(), [g[1] for g in added], [g[2] for g in added], n_act, act_log, 7)
+    for rel in ("yearly_details/settlements.csv", "yearly_details/generators.csv", "operation_logs/generator_operation_logs.csv"):
+        assert open(os.path.join(ed, rel), encoding="utf-8").read() == want[rel], rel
+    offs = open(os.path.join(ed, "yearly_details", "carbon_offsets.csv"), encoding="utf-8").read().split("\n")
+    woffs = want["yearly_details/carbon_offsets.csv"].split("\n")
+    assert len(offs) == len(woffs) and [l.split(",")[:10] for l in offs] == [l.split(",")[:10] for l in woffs]      # ids, coordinates, sizes
     summary = open(os.path.join(ed, "simulation_summary.csv"), encoding="utf-8").read().split("\n")
     assert summary[0] == "Simulation Summary" and summary[1] == "Timestamp," + exports[0]
     assert summary[4] == "Final Net Emissions (tonnes CO2)," + repr(d["best_metrics"]["final_net_emissions"]).rstrip("0").rstrip(".")

