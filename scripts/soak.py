@@ -1,9 +1,11 @@
 """Soak test on the GPU box (not part of pytest: minutes, not seconds).
   python scripts/soak.py [trials]
-Every trial draws a random policy (perturbed tables, stall, rates, random best lists), runs 1,536 episodes through BOTH
-kernels (helper-wave and single-wave) and demands identical bytes, checks 48 random episodes against the tabled CPU
-oracle bit for bit, and then takes 6 training steps on the device and on the host from that policy and demands identical
-policies.  Exit code 0 = everything matched."""
+Every trial draws a random policy (perturbed tables, stall, rates, random best lists — every fourth trial long ones, so that
+the replay episodes place hundreds of generators), runs 1,536 episodes through BOTH kernels (helper-wave and single-wave),
+and through an engine without the penalty-field pool (every search the exact scan), and demands identical bytes, checks 48
+random episodes against the tabled CPU oracle bit for bit, and then takes 6 training steps on the device and on the host
+from that policy and demands identical policies, and the independent restatement of the batch update within 1e-12 of them.
+Exit code 0 = everything matched."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,14 +20,20 @@ engines = {}
 for mode in ("0", "all"):
     os.environ["EIRGRID_HELPER_WAVES"] = mode
     engines[mode] = Engine(world, device=0)
-del os.environ["EIRGRID_HELPER_WAVES"]
+os.environ["EIRGRID_HELPER_WAVES"] = "0"; os.environ["EIRGRID_HEAVY_SLOTS"] = "0"
+engines["exact"] = Engine(world, device=0)
+del os.environ["EIRGRID_HELPER_WAVES"]; del os.environ["EIRGRID_HEAVY_SLOTS"]
 dev = Engine(world, device=0)
 tb = O.OracleTables(HostTables(world), len(world.existing_x))
 rng = np.random.default_rng(int(time.time()) if len(sys.argv) > 2 else 20261004)
 t0 = time.time()
 for trial in range(trials):
     pol = ActionWeights()
+    heavy = trial % 4 == 3
     run = [rng.integers(0, 61, int(rng.choice([0, 0, 1, 2, 5, 9]))).tolist() for _ in range(26)]
+    if heavy:
+        types = rng.choice(15, int(rng.integers(1, 6)), replace=False)
+        run = [[int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(int(rng.integers(5, 15)))] for _ in range(26)]
     dfl = [(3 * rng.choice([8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14], int(rng.choice([0, 1, 2, 3])))).tolist() for _ in range(26)]
     nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
     pol.apply_episode([float(rng.choice([-5e4, 3e5])), 0.7, float(rng.choice([4e10, 9e11])), 1.0], nr,
@@ -41,8 +49,13 @@ for trial in range(trials):
     mask = (rng.uniform(size=n) < 0.2).astype(np.uint8)
     a = engines["0"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
     b = engines["all"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+    c = engines["exact"].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
     for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
         assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (trial, name)
+        assert getattr(a, name).tobytes() == getattr(c, name).tobytes(), (trial, name, "field path vs exact scan")
+    live = np.arange(a.gen_cell.shape[1])[None, :] < a.n_gens[:, None]      # (the buffers are not cleared between batches)
+    for name in ("gen_cell", "gen_pack"):
+        assert (getattr(a, name)[live] == getattr(b, name)[live]).all() and (getattr(a, name)[live] == getattr(c, name)[live]).all(), (trial, name)
     ok = np.flatnonzero(a.status == 0)
     for e in rng.choice(ok, min(48, len(ok)), replace=False):
         st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), seed + first + int(e), replay=bool(mask[e]))
@@ -55,14 +68,20 @@ for trial in range(trials):
     for name in ("iterations_without_improvement", "learning_rate", "exploration_rate", "has_count_weights"):
         devp.set(name, host.get(name))
     dev.push(devp)
+    ow = oracle_weights_like(devp)
     for step in range(6):
         f = first + step * 256
         m = ((np.arange(f, f + 256) % 3) == 0).astype(np.uint8) if host.get("has_best_actions") == 1 else None
         engines["0"].train_step(host, seed, f, 256, m, noise_seed=seed + step)
         dev.device_step(seed, f, 256, 3, seed + step)
+        res = dev.fetch(256)
+        O.reduced_batch_update(ow, res.status, res.metrics, res.n_run, res.n_def, res.run_log, res.def_log, noise_seed=seed + step)
     dev.pull(devp)
+    for x, y in zip(devp.tables()[:2], ow.tables()[:2]):
+        np.testing.assert_allclose(x, y, rtol=1e-12, atol=0, err_msg=f"trial {trial}: device policy vs independent restatement")
+    assert devp.lists(0) == ow.lists(0) and devp.get("iterations_without_improvement") == ow.get("stall")
     for x, y in zip(host.tables(), devp.tables()):
         assert x.tobytes() == y.tobytes(), (trial, "device vs host policy")
     assert host.lists(0) == devp.lists(0) and host.get("iterations_without_improvement") == devp.get("iterations_without_improvement")
-    print(f"trial {trial:3d} ok  ({time.time() - t0:.0f} s; failed episodes in batch: {int((a.status != 0).sum())})", flush=True)
+    print(f"trial {trial:3d} ok  ({time.time() - t0:.0f} s; failed episodes in batch: {int((a.status != 0).sum())}; most generators in an episode {int(a.n_gens.max())})", flush=True)
 print("soak: all", trials, "trials matched")
