@@ -402,7 +402,7 @@ def test_best_run_record_follows_the_best_episode(engine, world, tmp_path):
         dev.close()
 
 
-def test_device_resident_replicas_of_two_processes_stay_identical():
+def test_device_resident_replicas_of_two_processes_stay_identical(tmp_path):
     """Two processes (two ranks sharing cuda:0, gloo standing in for RCCL) run the device-resident multi-rank step —
     eg_device_rollout of the own shard, exchange of the 32 KB packets, eg_device_apply on both packets — and the
     host-driven step on the same shards: after 8 steps all four policies must be the same, bit for bit."""
@@ -427,17 +427,16 @@ for resident in (True, False):
     tr.sync()
     w, dw, _ = pol.tables()
     out.append(hashlib.sha256(w.tobytes() + dw.tobytes() + bytes(sum(pol.lists(0), []))).hexdigest() + ":%%d:%%d" %% (pol.get("iteration_count"), pol.get("iterations_without_improvement")))
-open(os.path.join(%r, "gpurun_out", "_two_rank_resident_%%d.txt" %% rank), "w").write(out[0] + " " + out[1])
+open(os.path.join(%r, "_two_rank_resident_%%d.txt" %% rank), "w").write(out[0] + " " + out[1])
 dist.barrier()
 dist.destroy_process_group()
-""" % (root, root)
-    script = os.path.join(root, "gpurun_out", "_two_rank_resident.py")
-    os.makedirs(os.path.dirname(script), exist_ok=True)
+""" % (root, str(tmp_path))
+    script = os.path.join(str(tmp_path), "_two_rank_resident.py")
     open(script, "w").write(code)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29544", script]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
-    res = [open(os.path.join(root, "gpurun_out", "_two_rank_resident_%d.txt" % k)).read().split() for k in (0, 1)]
+    res = [open(os.path.join(str(tmp_path), "_two_rank_resident_%d.txt" % k)).read().split() for k in (0, 1)]
     assert res[0][0] == res[0][1] == res[1][0] == res[1][1], res
     assert res[0][0].split(":")[1] == str(8 * 2 * 96)
