@@ -294,6 +294,11 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         }
     if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
     for (int i = nbox; i < 1024; ++i) box[i] = 7u << 18;
+    for (int k = 0; k < 16; ++k) {      // which classes block k of 64 entries holds (the list is sorted by class)
+      uint32_t m = 0;
+      for (int i = 64 * k; i < 64 * k + 64; ++i) if ((box[i] >> 18) < uint32_t(kRadiusClasses)) m |= 1u << (box[i] >> 18);
+      box[1024 + k] = m;
+    }
   }
   if (rc == EG_OK) {
     void* p = nullptr;

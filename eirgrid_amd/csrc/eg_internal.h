@@ -94,8 +94,8 @@ constexpr size_t offv = a16(t12 + 8 * kYears * kTypes);                     // [
 constexpr size_t offc = a16(offv + 8 * kYears * kOffsetTypes * kYears);     // [26][4][3]
 constexpr size_t cc = a16(offc + 8 * kYears * kOffsetTypes * kMults);       // [26][15][26][3][2]
 constexpr size_t ps = a16(cc + 8 * size_t(kYears) * kTypes * kYears * kMults * 2);   // PsRec [26][kMaxVariants][kPsStride]
-constexpr size_t hv_box = a16(ps + sizeof(PsRec) * size_t(kYears) * kMaxVariants * kPsStride);   // u32 [1024]: heavy episodes, eg_rollout.hip heavy_add
-constexpr size_t total = hv_box + 4 * 1024;
+constexpr size_t hv_box = a16(ps + sizeof(PsRec) * size_t(kYears) * kMaxVariants * kPsStride);   // u32 [1024 + 16]: heavy episodes, eg_rollout.hip heavy_add
+constexpr size_t total = hv_box + 4 * (1024 + 16);
 }  // namespace tab
 
 struct DevTables {

@@ -897,8 +897,10 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 // reference's replay records and applies every action twice, SURVEY Q15: 228-468 generators once a replay episode has
 // become the best strategy): the best-scoring cells are all taken, the scan goes 15-41 chunks deep, and such an episode
 // took 40x the time of a sampled one — a launch lasts as long as its slowest episode.
-// From kHeavyGens generators on, an episode keeps in global memory, per radius class, the product of the penalty factors
-// of all its generators for every cell: field[rc][cell] (year-independent; folded in any order, it only serves a bound).
+// From kHeavyGens generators on, an episode keeps in global memory, per radius class it searches for, the product of the
+// penalty factors of all its generators for every cell: field[rc][cell] (year-independent; folded in any order, it only
+// serves a bound).  A class's field is built when the episode first searches for a type of that class and kept up to date
+// from then on.
 // A search then is
 //   1. approx(c) = ((te * cf) * size) * field[rc][c] over the sorted candidates — one gather and three multiplications
 //      per candidate instead of a pass over the generator list — with the same stop rule as the exact scan
@@ -956,14 +958,20 @@ __device__ __forceinline__ int heavy_claim(const DevTables& T, int lane) {
 // multiplies and stores.  Entries are distinct, so the order is free.  A wave costs four cycles per instruction whatever
 // it does, so this is written for instruction count: the list spares the index arithmetic of walking six boxes.
 constexpr int kBoxEntries = 1024, kBoxPerLane = kBoxEntries / kWave;
-struct __align__(16) SmemHeavy { uint32_t box[kBoxEntries]; };      // di + 16 | (dj + 16) << 5 | q << 10 | class << 18 (class 7: padding)
+struct __align__(16) SmemHeavy {
+  uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 | class << 18 (class 7: padding); sorted by class
+  uint32_t slot_classes[kBoxPerLane];      // bit rc: block k of 64 entries holds entries of class rc
+};
 __shared__ SmemHeavy sh;
 __device__ __forceinline__ void load_heavy_tables(const DevTables& T, int lane) {
   const uint32_t* src = reinterpret_cast<const uint32_t*>(T.base + tab::hv_box);
   for (int i = lane; i < kBoxEntries; i += kWave) sh.box[i] = src[i];
+  if (lane < kBoxPerLane) sh.slot_classes[lane] = src[kBoxEntries + lane];
 }
+// `classes`: the radius classes whose field this episode maintains (bit rc) — a class joins when the episode first searches
+// for a type of that class (heavy_build_class); blocks of the list that hold none of them are skipped.
 template <bool kLatency>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell) {
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int classes) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -972,10 +980,11 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
   double val[kBoxPerLane], fac[kBoxPerLane]; int off[kBoxPerLane];
 #pragma unroll
   for (int k = 0; k < kBoxPerLane; ++k) {
+    off[k] = -1; fac[k] = 1.0; val[k] = 1.0;
+    if ((__builtin_amdgcn_readfirstlane((int)sh.slot_classes[k]) & classes) == 0) continue;      // uniform
     const uint32_t en = sh.box[k * kWave + lane];
     const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 18);
-    off[k] = -1; fac[k] = 1.0; val[k] = 1.0;
-    if (rc < kRadiusClasses && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {
+    if (((classes >> rc) & 1) && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {      // (padding: class 7, never set)
       fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
       off[k] = rc * kFieldStride + ci * kGrid + cj;
       val[k] = field_load(base + off[k]);
@@ -984,26 +993,38 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 #pragma unroll
   for (int k = 0; k < kBoxPerLane; ++k)
     if (off[k] >= 0) base[off[k]] = val[k] * fac[k];
-  // (the stores are left in flight: whoever reads the field next — place_heavy, heavy_enter's loop — waits for them first)
+  // (the stores are left in flight: whoever reads the field next — place_heavy, heavy_build_class — waits for them first)
 #ifdef EG_STAMPS
   if (lane == 0) sm.hdbg[0][3] += __builtin_readcyclecounter() - ts0;
 #endif
 }
-// the episode turns heavy: all ones, then every generator placed so far
+// A class joins: its field = for every cell the product of the factors of the generators placed so far (any order: the
+// field only serves a bound), 64 cells at a time, the generator list read from LDS.
 template <bool kLatency>
-__device__ __noinline__ void heavy_enter(unsigned long long field_addr, int lane, int ngen) {
-  const GlobalF64 f = (GlobalF64)field_addr;
-  for (int i = lane; i < kRadiusClasses * kFieldStride; i += kWave) f[i] = 1.0;
+__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int ngen) {
+  const GlobalF64 f = (GlobalF64)class_addr;
+  constexpr int kChunks = (kCells + kWave - 1) / kWave;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int g = 0; g < ngen; ++g) {
-    heavy_add<kLatency>(field_addr, lane, (int)(sm.gcell[g] & 0xFFF));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next generator's box may overlap this one's
+  for (int ch = 0; ch < kChunks; ++ch) {
+    const int cell = ch * kWave + lane;
+    const int ci = cell / kGrid, cj = cell - ci * kGrid;
+    double p = 1.0;
+    for (int g = 0; g < ngen; ++g) {
+      const int gc = (int)(sm.gcell[g] & 0xFFF);      // the same entry in every lane
+      const int gi = gc / kGrid, gj = gc - gi * kGrid;
+      int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
+      q = q < kD2Max ? q : kD2Max;
+      p = p * factor_by_q<kLatency>(rc, q);
+    }
+    if (cell < kCells) f[cell] = p;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // The reference's product for ONE candidate cell: te times the factor of every generator in list order.  The lanes take a
-// generator each for the factors (64 at a time); the product itself is the sequential chain, three instructions per
-// generator (two v_readlane, one v_mul_f64) against the six or seven of chunk_product, which evaluates 64 candidates at
-// once — and a heavy search has one candidate, rarely two.
+// generator each for the factors (64 at a time).  A generator at or beyond the radius has the factor 1.0 and x * 1.0 == x
+// exactly, so only the generators inside the radius are multiplied in — in list order, as a sequential chain of v_mul_f64
+// fed by v_readlane.  The winner of a search is a cell that few generators reach: a handful of multiplications instead
+// of one per generator (chunk_product, which evaluates 64 different candidates at once, cannot skip anything).
 template <bool kLatency>
 __device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double te, int cell, int lane) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
@@ -1017,13 +1038,12 @@ __device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double
       q = q < kD2Max ? q : kD2Max;
       f = factor_by_q<kLatency>(rc, q);
     }
-    const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-    int j = 0;
-    for (; j + 4 <= cnt; j += 4) {
-      const double f0 = readlane_f64(f, j), f1 = readlane_f64(f, j + 1), f2 = readlane_f64(f, j + 2), f3 = readlane_f64(f, j + 3);
-      s = s * f0; s = s * f1; s = s * f2; s = s * f3;
+    unsigned long long near = __ballot(f != 1.0);
+    while (near != 0ull) {
+      const int j = __ffsll((long long)near) - 1;
+      s = s * readlane_f64(f, j);
+      near &= near - 1ull;
     }
-    for (; j < cnt; ++j) s = s * readlane_f64(f, j);
   }
   return s;
 }
@@ -1244,6 +1264,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   unsigned long long bytes;           // algorithmic bytes of SURVEY §8(d): whole numbers, kept as an integer (scalar registers)
   int chunks;                         // 64-candidate chunks of sorted candidate records (32 B each) the searches requested
   int heavy;                          // field slot of a heavy episode (place_heavy); -1: not asked for yet, -2: none to be had
+  int heavy_classes;                  // bit rc: the field of radius class rc is built and kept up to date
 };
 
 // ---- batch ("reduced") update statistics --------------------------------------------------------------------
@@ -1412,7 +1433,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
   EG_MARKG(16);
 
   Episode ep;
-  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0; ep.heavy = -1;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0; ep.heavy = -1; ep.heavy_classes = 0;
   uint8_t* run_log = O.run_log(e);
   uint8_t* def_log = O.def_log(e);
   uint8_t* act_log = O.act_log(e);
@@ -1603,18 +1624,19 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         bool placed = false;
         if constexpr (kHeavy) if (ep.ngen >= kHeavyGens && ep.heavy != -2) {      // a long list: approximate field + exact evaluation of the few candidates
           const unsigned long long slot_bytes = (unsigned long long)(kRadiusClasses * kFieldStride) * 8ull;
-          if (ep.heavy == -1) {
-            ep.heavy = heavy_claim(T, lane);
-            if (ep.heavy >= 0) heavy_enter<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes, lane, ep.ngen);
-          }
+          if (ep.heavy == -1) ep.heavy = heavy_claim(T, lane);
           if (ep.heavy >= 0) {
             const int info = __builtin_amdgcn_readfirstlane(sm.type_info[t]);
             const int hv = info & 15, hrc = (info >> 4) & 15;
+            const unsigned long long class_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull;
+            if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
+              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, ep.ngen);
+              ep.heavy_classes |= 1 << hrc;
+            }
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
 #endif
-            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride),
-                                                        (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull,
+            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride), class_addr,
                                                         T.size_factor, lane, hrc, ep.ngen);
 #ifdef EG_STAMPS
             const unsigned long long th1 = __builtin_readcyclecounter();
@@ -1654,7 +1676,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
-        if constexpr (kHeavy) if (ep.heavy >= 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), lane, cell);
+        if constexpr (kHeavy) if (ep.heavy_classes != 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), lane, cell, ep.heavy_classes);
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
