@@ -906,7 +906,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
 //      per candidate instead of a pass over the generator list — with the same stop rule as the exact scan
 //      (field <= 1, so approx(c) <= base(c));
 //   2. every candidate with approx >= M * (1 - 2^-30), M the largest approx, is evaluated EXACTLY: the reference's
-//      product in list order (chunk_product), first maximum in cell order (chunk_reduce).
+//      product in list order (exact_product_chain; chunk_product when there are many ties), first maximum in cell order.
 // Exactness: exact(c) and approx(c) are both the real product te * cf * size * prod f rounded at most G + 3 times each,
 // so they differ by less than 2 (G + 3) 2^-53 < 2^-42 relative while no intermediate is subnormal; the arg-max of the
 // exact scores (and every cell tied with it) therefore lies within 2^-41 of M and is among the candidates, and a cell
@@ -969,8 +969,9 @@ __device__ __forceinline__ void load_heavy_tables(const DevTables& T, int lane) 
   if (lane < kBoxPerLane) sh.slot_classes[lane] = src[kBoxEntries + lane];
 }
 // `classes`: the radius classes whose field this episode maintains (bit rc) — a class joins when the episode first searches
-// for a type of that class (heavy_build_class); blocks of the list that hold none of them are skipped.
-template <bool kLatency>
+// for a type of that class (heavy_build_class); blocks of the list that hold none of them are skipped.  kAll: every class
+// is maintained (what a replay of a mixed list comes to after a few years): no tests (they cost a third more instructions).
+template <bool kLatency, bool kAll>
 __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int classes) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
@@ -981,10 +982,10 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 #pragma unroll
   for (int k = 0; k < kBoxPerLane; ++k) {
     off[k] = -1; fac[k] = 1.0; val[k] = 1.0;
-    if ((__builtin_amdgcn_readfirstlane((int)sh.slot_classes[k]) & classes) == 0) continue;      // uniform
+    if constexpr (!kAll) if ((__builtin_amdgcn_readfirstlane((int)sh.slot_classes[k]) & classes) == 0) continue;      // uniform
     const uint32_t en = sh.box[k * kWave + lane];
     const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 18);
-    if (((classes >> rc) & 1) && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {      // (padding: class 7, never set)
+    if ((kAll ? rc < kRadiusClasses : (((classes >> rc) & 1) != 0)) && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {      // (padding: class 7)
       fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
       off[k] = rc * kFieldStride + ci * kGrid + cj;
       val[k] = field_load(base + off[k]);
@@ -999,25 +1000,32 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 #endif
 }
 // A class joins: its field = for every cell the product of the factors of the generators placed so far (any order: the
-// field only serves a bound), 64 cells at a time, the generator list read from LDS.
+// field only serves a bound).  The field of the 41 blocks of 64 cells sits in registers while the generators pass by; a
+// generator only touches the blocks whose rows come within `reach` of its own row (a scalar test per block).
 template <bool kLatency>
-__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int ngen) {
+__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int reach, int ngen) {
   const GlobalF64 f = (GlobalF64)class_addr;
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int ch = 0; ch < kChunks; ++ch) {
-    const int cell = ch * kWave + lane;
-    const int ci = cell / kGrid, cj = cell - ci * kGrid;
-    double p = 1.0;
-    for (int g = 0; g < ngen; ++g) {
-      const int gc = (int)(sm.gcell[g] & 0xFFF);      // the same entry in every lane
-      const int gi = gc / kGrid, gj = gc - gi * kGrid;
+  double p[kChunks];
+#pragma unroll
+  for (int ch = 0; ch < kChunks; ++ch) p[ch] = 1.0;
+  for (int g = 0; g < ngen; ++g) {
+    const int gc = __builtin_amdgcn_readfirstlane((int)(sm.gcell[g] & 0xFFF));
+    const int gi = gc / kGrid, gj = gc - gi * kGrid;
+    const int row_lo = gi - reach, row_hi = gi + reach;
+#pragma unroll
+    for (int ch = 0; ch < kChunks; ++ch) {
+      if ((ch * kWave + kWave - 1) / kGrid < row_lo || (ch * kWave) / kGrid > row_hi) continue;      // uniform: constants against scalars
+      const int cell = ch * kWave + lane;
+      const int ci = cell / kGrid, cj = cell - ci * kGrid;
       int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
       q = q < kD2Max ? q : kD2Max;
-      p = p * factor_by_q<kLatency>(rc, q);
+      p[ch] = p[ch] * factor_by_q<kLatency>(rc, q);
     }
-    if (cell < kCells) f[cell] = p;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
+#pragma unroll
+  for (int ch = 0; ch < kChunks; ++ch) { const int cell = ch * kWave + lane; if (cell < kCells) f[cell] = p[ch]; }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // The reference's product for ONE candidate cell: te times the factor of every generator in list order.  The lanes take a
@@ -1630,7 +1638,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
             const int hv = info & 15, hrc = (info >> 4) & 15;
             const unsigned long long class_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull;
             if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
-              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, ep.ngen);
+              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, (info >> 8) & 15, ep.ngen);
               ep.heavy_classes |= 1 << hrc;
             }
 #ifdef EG_STAMPS
@@ -1676,7 +1684,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
-        if constexpr (kHeavy) if (ep.heavy_classes != 0) heavy_add<(kHelpers > 0)>((unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull), lane, cell, ep.heavy_classes);
+        if constexpr (kHeavy) if (ep.heavy_classes != 0) {
+          const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
+          if (ep.heavy_classes == (1 << kRadiusClasses) - 1) heavy_add<(kHelpers > 0), true>(field_addr, lane, cell, ep.heavy_classes);
+          else heavy_add<(kHelpers > 0), false>(field_addr, lane, cell, ep.heavy_classes);
+        }
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
