@@ -1418,8 +1418,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
   load_state(S);
   // iteration.rs:34-42: which episodes replay the best strategy comes from the caller's mask or, when the policy lives on
   // the device (the host cannot know whether a best strategy exists yet), from a period over the global episode index
-  const bool replay = replay_mask != nullptr ? replay_mask[e] != 0
-                                             : (replay_period != 0u && S.has_best_actions && (first_index + e) % replay_period == 0ull);
+  // (Replay episodes always run the heavy-capable variant — the launch plan sends them there, eg_api.cpp launch_batch —, so
+  //  the lean variant carries no replay code at all.)
+  const bool replay = kHeavy && (replay_mask != nullptr ? replay_mask[e] != 0
+                                                        : (replay_period != 0u && S.has_best_actions && (first_index + e) % replay_period == 0ull));
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
   unsigned long long stamps[32] = {};
@@ -1517,6 +1519,18 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
     //      phase 1 = additional actions (simulation.rs:144-198).  One loop so that apply_action is emitted once. ----
     EG_MARKG(18);
     int replay_idx = 0, replay_def_idx = 0;   // replay_index is keyed per year (sampling.rs:82, :246-247)
+    // a replay episode reads this year's lists once: offsets as scalars, the first 128 / 64 entries one per lane (an action is
+    // then a v_readlane instead of two dependent global round trips per action)
+    int rep_lo = 0, rep_n = 0, repd_lo = 0, repd_n = 0, rep0 = 0, rep1 = 0, repd0 = 0;
+    if constexpr (kHeavy) if (replay) {
+      rep_lo = __builtin_amdgcn_readfirstlane(S.best_off()[yi]); rep_n = __builtin_amdgcn_readfirstlane(S.best_off()[yi + 1]) - rep_lo;
+      repd_lo = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi]); repd_n = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi + 1]) - repd_lo;
+      if (!S.has_best_actions) rep_n = 0;
+      if (!S.has_best_deficit) repd_n = 0;
+      rep0 = lane < rep_n ? (int)S.best_actions()[rep_lo + lane] : 0;
+      rep1 = kWave + lane < rep_n ? (int)S.best_actions()[rep_lo + kWave + lane] : 0;
+      repd0 = lane < repd_n ? (int)S.bestd_actions()[repd_lo + lane] : 0;
+    }
     const State year_start = state_of(a);
     int phase = year_start.balance < 0.0 ? 0 : 1;
     if (lane == 0) { sm.ystate[0] = year_start.net; sm.ystate[1] = year_start.opinion; sm.ystate[2] = year_start.balance; sm.ystate[3] = year_start.cost; }
@@ -1561,9 +1575,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         EG_MARKG(19);
         if (attempts < 5u) {
           if (replay) {   // sampling.rs:242-313
-            const int lo = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi]), n = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi + 1]) - lo;
-            if (S.has_best_deficit && replay_def_idx < n) { action = S.bestd_actions()[lo + replay_def_idx]; replay_def_idx += 1; }
-            else action = smart_deficit_fallback(rng, lane);
+            if (replay_def_idx < repd_n) {
+              action = replay_def_idx < kWave ? __builtin_amdgcn_readlane(repd0, replay_def_idx) : (int)S.bestd_actions()[repd_lo + replay_def_idx];
+              replay_def_idx += 1;
+            } else action = smart_deficit_fallback(rng, lane);
             if (ep.def_pos >= EG_DEF_CAP || ep.n_def_y >= 128) { ep.status = EG_EP_OVERFLOW; break; }
             if (lane == 0) { def_log[ep.def_pos] = (uint8_t)action; sm.ydef[ep.n_def_y] = (uint8_t)action; }
             ep.def_pos += 1; ep.n_def_y += 1;
@@ -1577,7 +1592,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
           n_add_known = true;
           EG_MARKG(24);
           if (replay) {
-            n_add = S.has_best_actions ? (uint32_t)(S.best_off()[yi + 1] - S.best_off()[yi]) : 0u;
+            n_add = (uint32_t)rep_n;
           } else {   // sampling.rs:380-443
             const uint32_t dcount = (uint32_t)ep.n_def_y;
             const uint32_t cap = dcount >= 20u ? 0u : 20u - dcount;
@@ -1602,9 +1617,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         k_add += 1;
         EG_MARKG(19);
         if (replay) {   // sampling.rs:78-145
-          const int lo = __builtin_amdgcn_readfirstlane(S.best_off()[yi]), n = __builtin_amdgcn_readfirstlane(S.best_off()[yi + 1]) - lo;
-          if (S.has_best_actions && replay_idx < n) { action = S.best_actions()[lo + replay_idx]; replay_idx += 1; }
-          else action = smart_fallback(rng, lane, year);
+          if (replay_idx < rep_n) {
+            action = replay_idx < kWave ? __builtin_amdgcn_readlane(rep0, replay_idx)
+                                        : (replay_idx < 2 * kWave ? __builtin_amdgcn_readlane(rep1, replay_idx - kWave) : (int)S.best_actions()[rep_lo + replay_idx]);
+            replay_idx += 1;
+          } else action = smart_fallback(rng, lane, year);
           if (ep.run_pos >= EG_RUN_CAP) { ep.status = EG_EP_OVERFLOW; break; }
           if (lane == 0) run_log[ep.run_pos] = (uint8_t)action;
           ep.run_pos += 1; ep.n_run_y += 1;
