@@ -293,11 +293,10 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
           ++nbox;
         }
     if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
-    for (int i = nbox; i < 1024; ++i) box[i] = 7u << 18;
-    for (int k = 0; k < 16; ++k) {      // which classes block k of 64 entries holds (the list is sorted by class)
-      uint32_t m = 0;
-      for (int i = 64 * k; i < 64 * k + 64; ++i) if ((box[i] >> 18) < uint32_t(kRadiusClasses)) m |= 1u << (box[i] >> 18);
-      box[1024 + k] = m;
+    for (int i = nbox; i < 1024; ++i) box[i] = 145u << 10;      // padding: class 0, di = dj = -16 (no class reaches that far), q = 145 (factor 1.0)
+    for (int k = 0, i = 0; k <= kRadiusClasses; ++k) {      // words 1024..1030: where class k starts (the list is sorted by class), then the end
+      while (i < nbox && i < 1024 && int(box[i] >> 18) < k) ++i;
+      box[1024 + k] = uint32_t(i);
     }
   }
   if (rc == EG_OK) {

@@ -954,46 +954,61 @@ __device__ __forceinline__ int heavy_claim(const DevTables& T, int lane) {
 // field[rc][c] *= d/R of a generator at `cell`, for every class and every cell closer than the class radius.  The cells
 // concerned are the same for every generator up to a translation: the host lists them once (eg_api.cpp, tab::hv_box: 978
 // entries {di, dj, squared distance, class} for the reference's six radii, padded to 1024 = 16 per lane) and the heavy
-// variant keeps the list in LDS.  One memory round trip: every lane requests its (at most) 16 field entries, then
-// multiplies and stores.  Entries are distinct, so the order is free.  A wave costs four cycles per instruction whatever
-// it does, so this is written for instruction count: the list spares the index arithmetic of walking six boxes.
-constexpr int kBoxEntries = 1024, kBoxPerLane = kBoxEntries / kWave;
+// variant keeps the list in LDS.  One memory round trip: every lane requests its 16 field entries, then multiplies and
+// stores.  Entries are distinct, so the order is free.
+// There is NO control flow in here, on purpose.  With a branch around every entry (skip cells outside the grid, skip
+// classes this episode does not search) the compiler can no longer count which loads are outstanding: it waited for
+// vmcnt(0) before every multiplication — that is, for the previous STORE to come back from L2 — and for every list
+// entry before the next was requested: 8-12 thousand cycles per generator, measured, for what is one round trip.  So an
+// entry that falls outside the grid goes to a spare entry behind its class's cells (kFieldStride > kCells; never read),
+// and the padding of the list multiplies a cell no class reaches by exactly 1.0.  Classes the episode keeps no field for
+// are not in its list at all: heavy_pack_list rewrites the list in LDS whenever a class joins (bytes count as much as
+// round trips here: a thousand and more such episodes share the L2), and the update comes in four lengths.
+constexpr int kBoxEntries = 1024;
+constexpr uint32_t kBoxPadding = 145u << 10;      // class 0, di = dj = -16, q = 145: a factor of exactly 1.0 (sm.dr is padded with it)
 struct __align__(16) SmemHeavy {
-  uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 | class << 18 (class 7: padding); sorted by class
-  uint32_t slot_classes[kBoxPerLane];      // bit rc: block k of 64 entries holds entries of class rc
+  uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 | class << 18
 };
 __shared__ SmemHeavy sh;
-__device__ __forceinline__ void load_heavy_tables(const DevTables& T, int lane) {
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(T.base + tab::hv_box);
-  for (int i = lane; i < kBoxEntries; i += kWave) sh.box[i] = src[i];
-  if (lane < kBoxPerLane) sh.slot_classes[lane] = src[kBoxEntries + lane];
+typedef const uint32_t __attribute__((address_space(1)))* GlobalU32c;
+// sh.box = the entries of the radius classes in `classes` (the host's list is sorted by class; its words 1024..1030 are where
+// each class starts), padded to a multiple of four per lane; returns that multiple (1..4)
+__device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, int lane, int classes) {
+  const GlobalU32c src = (GlobalU32c)box_addr;
+  int n = 0;
+  for (int rc = 0; rc < kRadiusClasses; ++rc) {
+    if (!((classes >> rc) & 1)) continue;
+    const int s0 = __builtin_amdgcn_readfirstlane((int)src[kBoxEntries + rc]), s1 = __builtin_amdgcn_readfirstlane((int)src[kBoxEntries + rc + 1]);
+    for (int i = s0 + lane; i < s1; i += kWave) sh.box[n + i - s0] = src[i];
+    n += s1 - s0;
+  }
+  const int padded = (n + 4 * kWave - 1) & ~(4 * kWave - 1);
+  for (int i = n + lane; i < padded; i += kWave) sh.box[i] = kBoxPadding;
+  wave_sync();
+  return padded / (4 * kWave);
 }
-// `classes`: the radius classes whose field this episode maintains (bit rc) — a class joins when the episode first searches
-// for a type of that class (heavy_build_class); blocks of the list that hold none of them are skipped.  kAll: every class
-// is maintained (what a replay of a mixed list comes to after a few years): no tests (they cost a third more instructions).
-template <bool kLatency, bool kAll>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int classes) {
+template <bool kLatency, int kPerLane>
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
   const int gi = cell / kGrid, gj = cell - gi * kGrid;
   const GlobalF64 base = (GlobalF64)field_addr;
-  double val[kBoxPerLane], fac[kBoxPerLane]; int off[kBoxPerLane];
+  double val[kPerLane], fac[kPerLane]; int off[kPerLane]; uint32_t ens[kPerLane];
 #pragma unroll
-  for (int k = 0; k < kBoxPerLane; ++k) {
-    off[k] = -1; fac[k] = 1.0; val[k] = 1.0;
-    if constexpr (!kAll) if ((__builtin_amdgcn_readfirstlane((int)sh.slot_classes[k]) & classes) == 0) continue;      // uniform
-    const uint32_t en = sh.box[k * kWave + lane];
+  for (int k = 0; k < kPerLane; ++k) ens[k] = sh.box[k * kWave + lane];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all list entries in one LDS round trip, not one after the other)
+#pragma unroll
+  for (int k = 0; k < kPerLane; ++k) {
+    const uint32_t en = ens[k];
     const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 18);
-    if ((kAll ? rc < kRadiusClasses : (((classes >> rc) & 1) != 0)) && (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid) {      // (padding: class 7)
-      fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
-      off[k] = rc * kFieldStride + ci * kGrid + cj;
-      val[k] = field_load(base + off[k]);
-    }
+    const bool inside = (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid;
+    fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
+    off[k] = rc * kFieldStride + (inside ? ci * kGrid + cj : kCells);
+    val[k] = field_load(base + off[k]);
   }
 #pragma unroll
-  for (int k = 0; k < kBoxPerLane; ++k)
-    if (off[k] >= 0) base[off[k]] = val[k] * fac[k];
+  for (int k = 0; k < kPerLane; ++k) base[off[k]] = val[k] * fac[k];
   // (the stores are left in flight: whoever reads the field next — place_heavy, heavy_build_class — waits for them first)
 #ifdef EG_STAMPS
   if (lane == 0) sm.hdbg[0][3] += __builtin_readcyclecounter() - ts0;
@@ -1273,6 +1288,7 @@ struct Episode {   // wave-uniform bookkeeping of one episode
   int chunks;                         // 64-candidate chunks of sorted candidate records (32 B each) the searches requested
   int heavy;                          // field slot of a heavy episode (place_heavy); -1: not asked for yet, -2: none to be had
   int heavy_classes;                  // bit rc: the field of radius class rc is built and kept up to date
+  int heavy_quads;                    // list entries per lane / 4 of the field update (heavy_pack_list)
 };
 
 // ---- batch ("reduced") update statistics --------------------------------------------------------------------
@@ -1433,7 +1449,6 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
   if (kHeavy && lane < 8) sm.hdbg[lane >> 2][lane & 3] = 0ull;
 #endif
   load_static_tables(T, lane, kHelpers == 0 || kHeavy);      // (the heavy variant's field update reads sm.dr / sl.dr16)
-  if constexpr (kHeavy) load_heavy_tables(T, lane);
   // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
   const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
                                                  T.pre_tg()[lane] == T.pre_tg()[lane - 1] && T.pre_ig()[lane] == T.pre_ig()[lane - 1] &&
@@ -1443,7 +1458,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
   EG_MARKG(16);
 
   Episode ep;
-  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0; ep.heavy = -1; ep.heavy_classes = 0;
+  ep.ngen = 0; ep.noff = 0; ep.run_pos = 0; ep.def_pos = 0; ep.act_pos = 0; ep.status = EG_EP_OK; ep.bytes = 32ull; ep.chunks = 0; ep.heavy = -1; ep.heavy_classes = 0; ep.heavy_quads = 0;
   uint8_t* run_log = O.run_log(e);
   uint8_t* def_log = O.def_log(e);
   uint8_t* act_log = O.act_log(e);
@@ -1657,6 +1672,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
             if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
               heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, (info >> 8) & 15, ep.ngen);
               ep.heavy_classes |= 1 << hrc;
+              ep.heavy_quads = heavy_pack_list((unsigned long long)(T.base + tab::hv_box), lane, ep.heavy_classes);
             }
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
@@ -1703,8 +1719,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         a.opcnt += 1;
         if constexpr (kHeavy) if (ep.heavy_classes != 0) {
           const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
-          if (ep.heavy_classes == (1 << kRadiusClasses) - 1) heavy_add<(kHelpers > 0), true>(field_addr, lane, cell, ep.heavy_classes);
-          else heavy_add<(kHelpers > 0), false>(field_addr, lane, cell, ep.heavy_classes);
+          switch (ep.heavy_quads) {      // (uniform)
+            case 1: heavy_add<(kHelpers > 0), 4>(field_addr, lane, cell); break;
+            case 2: heavy_add<(kHelpers > 0), 8>(field_addr, lane, cell); break;
+            case 3: heavy_add<(kHelpers > 0), 12>(field_addr, lane, cell); break;
+            default: heavy_add<(kHelpers > 0), 16>(field_addr, lane, cell); break;
+          }
         }
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
