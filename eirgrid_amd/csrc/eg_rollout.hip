@@ -1187,8 +1187,8 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   if (lane == 0) sm.hres[1].m03 = b.m03;
   wave_sync();
   // requested, in units of 2 KB (= a chunk of 64 records): the K chunks scanned and the winner's chunk (a second pass re-reads
-  // the first pass's records), K x 64 field entries of 8 B, and the field update that follows (978 entries read and written)
-  return b.cell | ((K + 1 + (K + 3) / 4 + 8) << 16);
+  // the first pass's records) and K x 64 field entries of 8 B (the field update that follows bills itself)
+  return b.cell | ((K + 1 + (K + 3) / 4) << 16);
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
@@ -1719,6 +1719,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
         a.opcnt += 1;
         if constexpr (kHeavy) if (ep.heavy_classes != 0) {
           const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
+          ep.chunks += 2 * ep.heavy_quads;      // 256 entries of 8 B read and written per quad = 2 units of 2 KB
           switch (ep.heavy_quads) {      // (uniform)
             case 1: heavy_add<(kHelpers > 0), 4>(field_addr, lane, cell); break;
             case 2: heavy_add<(kHelpers > 0), 8>(field_addr, lane, cell); break;

@@ -2,11 +2,11 @@
 
   python scripts/pmc_summarize.py <tag> <out_dir> <workload>:<fetch_dir>:<write_dir> [...]
 
-Each dir is the -d directory of one counter pass of `python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline ...` of that
+Each dir is the -d directory of one counter pass of `python3 bench.py --steps 4 --warmup 20 --no-cpu-baseline --batches-per-step 2 ...` of that
 workload ("16384r0.1" = BASELINE configs[2], the default; "1024" = configs[1]).  A batch with replay episodes is two
 k_rollout grids (the heavy-capable variant `k_rollout<.., true>` for the replays, the lean one for the rest); the counters
 of a batch are the sum of its grids.  Only the dispatches of the TIMED region (the last steps x batches_per_step = 8 per
-variant) are averaged: the loop's cost per batch changes while the first best strategies are found.
+variant) are averaged, after 40 warm-up batches: the loop's cost per batch changes while the first best strategies are found.
 HBM bytes per batch = 2 * FETCH_SIZE * 1024 (gfx950: FETCH_SIZE counts half of a wide stream, MI355X_MICROARCH.md HBM
 section; an upper bound for narrow gathers) + WRITE_SIZE * 1024.  Counter collection serialises the dispatches, so
 `kernel_ns` (heavy + lean, one after the other) is longer than the overlapped launch of an un-profiled run.

@@ -17,8 +17,8 @@ cp $(ls $O/prof_${tag}_c2/*/*kernel_stats.csv | head -1) $O/${tag}_bench_c2_kern
 cp $(ls $O/prof_${tag}_c1/*/*kernel_stats.csv | head -1) $O/${tag}_bench_c1_kernel_stats.csv
 echo "kernel stats done"
 # counters: separate passes, nothing but --pmc (MI355X_MICROARCH.md, HBM / rocprofv3 section)
-P2="--steps 4 --warmup 2 --no-cpu-baseline --no-config1 --batches-per-step 2"
-P1="--steps 4 --warmup 2 --no-cpu-baseline --episodes 1024 --replay-fraction 0 --batches-per-step 2"
+P2="--steps 4 --warmup 20 --no-cpu-baseline --no-config1 --batches-per-step 2"
+P1="--steps 4 --warmup 20 --no-cpu-baseline --episodes 1024 --replay-fraction 0 --batches-per-step 2"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_${tag}_f_c2 --output-format csv -- python3 bench.py $P2 > $O/pmc_${tag}.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_${tag}_w_c2 --output-format csv -- python3 bench.py $P2 >> $O/pmc_${tag}.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_${tag}_f_c1 --output-format csv -- python3 bench.py $P1 >> $O/pmc_${tag}.log 2>&1

@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 tag, out_dir, specs = sys.argv[1], sys.argv[2], sys.argv[3:]
 TIMED = 8
 doc = {"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU "
-               "SQ_WAIT_ANY -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --batches-per-step 2 [...] (the training loop of that "
+               "SQ_WAIT_ANY -- python3 bench.py --steps 4 --warmup 20 --no-cpu-baseline --batches-per-step 2 [...] (the training loop of that "
                "workload); per-batch averages over the k_rollout dispatches of the timed region, heavy-variant grid + lean grid. "
                "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles summed over the SIMDs: valu_busy = SQ_ACTIVE_INST_VALU * 4 / "
                "(1024 SIMDs * duration * 2.4 GHz), duration = the grids one after the other (counter collection serialises dispatches; "

@@ -420,7 +420,9 @@ def test_heavy_episodes_match_the_oracle(world):
     tb = _tabled(world)
     rng = np.random.default_rng(11)
     policies = []
-    for per_year, types in ((12, list(range(15))), (9, [0, 4, 12]), (15, [1, 13, 14, 5, 7]), (17, [12])):
+    # (the field update comes in four lengths, by the entries of the radius classes an episode searches — heavy_pack_list: the type
+    #  lists below make it 4, 1, 4, 1, 2 and 3 quads of the entry list)
+    for per_year, types in ((12, list(range(15))), (9, [0, 4, 12]), (15, [1, 13, 14, 5, 7]), (17, [12]), (9, [5]), (10, [5, 6, 0])):
         pol = ActionWeights()
         run = [[int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(per_year)] for _ in range(26)]
         dfl = [[int(3 * rng.choice([8, 7, 12, 11])) for _ in range(int(rng.integers(0, 3)))] for _ in range(26)]
@@ -462,7 +464,7 @@ def test_heavy_episodes_match_the_oracle(world):
             assert_episode_equal(a, e, ref, f"policy {k}, {'replay' if mask[e] else 'sampled'}")
     assert heavy >= 100
     # the field path really ran: the same episodes take a fraction of the exact scan's time
-    print("k_rollout ms for the four batches:", {f"{k[0]}/{k[1]}": round(v, 2) for k, v in kernel_ms.items()})
+    print("k_rollout ms for the six batches:", {f"{k[0]}/{k[1]}": round(v, 2) for k, v in kernel_ms.items()})
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
 
 
