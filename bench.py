@@ -16,12 +16,20 @@ so that the K timed steps last at least --min-seconds (0.5 s) — `steps`, `warm
 `ms_per_step` is per step, `ms_per_batch` per pass.
 
 Reference semantics kept: a replay episode records and applies every action twice, so once a replay
-episode becomes the best strategy the replayed lists — and the generators each replay episode places — double.  The
-line reports what the loop did: `config.replay` (generators per replay / seeded episode, best-list length) and
+episode becomes the best strategy the replayed lists — and the generators each replay episode places — double.  Left to
+itself the loop therefore changes its own workload, and differently for every global batch size: from the seeded policy
+a replay episode places 228 generators at N = 1 for as long as the bench runs, while 4 x 16 384 episodes per update reach
+an 821-action best list within the warm-up (every replay then ends in EG_EP_OVERFLOW at 512 generators).  A benchmark
+needs the same work per GPU at every N, so by default every batch starts from the SAME policy — the seeded one, put back
+on the device before each batch by eg_policy_rewind (a device-to-device copy inside the timed region); the batch's update
+runs in full.  `--trajectory` lets the policy evolve instead (DESIGN.md §4 has those numbers).  The line reports what the
+batches did: `config.replay` (generators per replay / seeded episode, best-list length), `config.policy` and
 `config.episodes_failed` (EG_EP_OVERFLOW etc.; failed episodes are NOT counted in `value`).
 
-The line also carries `config1` (BASELINE configs[1]: 1 024 episodes per batch, no replay, its own timed region),
-`roofline` and `cpu_baseline` (N = 1).
+The N = 1 line also carries `config2_grown` (the same batches from the grown-replay state: the policy the single-GPU loop
+holds 48 batches after the seeded one, where a replay episode places 228 generators — what rounds 1-2 optimised and what
+`--grown` measures as the headline), `config1` (BASELINE configs[1]: 1 024 episodes per batch, no replay), each with a timed
+region and a `roofline` of its own, and `cpu_baseline`.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
@@ -41,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+GROW_BATCHES = 48     # free-running batches (single-GPU semantics) from the seeded policy to the grown-replay state
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable)
 CUS, SIMDS_PER_CU = 256, 4
 
@@ -100,7 +109,7 @@ def sq_counters(workload: str):
     except (KeyError, ZeroDivisionError):
         return None
     out = {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / max(run.get("episodes_per_launch", 1), 1)}
-    for v in ("heavy", "lean"):      # a batch with replay episodes: the two grids of the launch, measured one after the other
+    for v in ("heavy", "short", "lean"):      # a batch with replay episodes: the grids of the launch, measured one after the other
         if isinstance(run.get(v), dict) and "valu_busy" in run[v]:
             out[f"valu_busy_{v}_grid"] = run[v]["valu_busy"]
     return out
@@ -228,11 +237,18 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the K timed steps last at least this long (batches_per_step is sized for it)")
     ap.add_argument("--batches-per-step", type=int, default=0, help="fix it instead of calibrating (0 = calibrate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-config1", action="store_true", help="skip the second object (configs[1]: 1024 episodes, no replay)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the secondary objects (configs[1]: 1024 episodes, no replay; the grown-replay state)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsal)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="rehearsal: initialise torch.distributed and issue the per-update collectives even with one rank")
+    ap.add_argument("--grown", action="store_true",
+                    help="measure the grown-replay state instead of the seeded one: the policy the single-GPU training loop holds after "
+                         f"{GROW_BATCHES} batches from the seeded policy (best list 257 actions, a replay episode places 228 generators); the N = 1 "
+                         "line carries that measurement as its `config2_grown` object anyway")
+    ap.add_argument("--trajectory", action="store_true",
+                    help="let the policy evolve from batch to batch (the training loop as it runs) instead of starting every batch "
+                         "from the seeded policy; what a replay episode costs then depends on the run and on N (SURVEY Q15)")
     ap.add_argument("--no-yearly", action="store_true", help="skip the 26x21 yearly rows (the reference always produces them)")
     args = ap.parse_args()
 
@@ -272,16 +288,30 @@ def main():
 
     world = synthetic_world()
     eng = Engine(world, device=local_rank)
-    weights = ActionWeights()
-    if args.replay_fraction > 0.0:
-        # the replayed best-action list is config 1's episode (seed 12345, global index 0) — installed
-        # by the reference's own sequential update (multi_simulation.rs:494-508) of that one episode, on every rank alike
-        first = eng.run_iteration(0, weights, False, args.seed)
-        weights.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
-                              first.def_log[0, :first.n_def[0].sum()])
+    def seeded_policy(grown: bool):
+        """SURVEY §8(d) config 3: a fresh ActionWeights::new whose best-action list is config 1's episode (seed 12345, global index
+        0) — installed by the reference's own sequential update (multi_simulation.rs:494-508) of that one episode, on every rank
+        alike.  grown: plus GROW_BATCHES batches of the single-GPU training loop from there (every rank runs the same ones, no
+        exchange): replay episodes win, and every win doubles the replayed list (Q15) until it has 257 actions."""
+        w = ActionWeights()
+        if args.replay_fraction > 0.0:
+            first = eng.run_iteration(0, w, False, args.seed)
+            w.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
+                            first.def_log[0, :first.n_def[0].sum()])
+            if grown:
+                grow = BatchTrainer(eng, w, args.episodes, args.seed, 0, 1, None, replay_fraction=args.replay_fraction,
+                                    write_yearly=not args.no_yearly, device_resident=True)
+                for _ in range(GROW_BATCHES):
+                    grow.step()
+                grow.sync()
+        return w
+
+    weights = seeded_policy(args.grown)
     trainer = BatchTrainer(eng, weights, args.episodes, args.seed, rank, world_size, dist if use_dist else None,
                            replay_fraction=args.replay_fraction, write_yearly=not args.no_yearly,
-                           force_collectives=args.force_collectives)
+                           force_collectives=args.force_collectives, device_resident=True)
+    if not args.trajectory:
+        trainer.pin_policy()
 
     def fence():
         if use_dist:
@@ -295,65 +325,104 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---- calibration (untimed for the result): the loop's cost per batch changes while the first best strategies are
-    #      found (replay episodes grow, Q15), so it is taken from the LAST passes of 10 ----
-    bps = args.batches_per_step
-    calibration = 0
-    if bps <= 0:
-        for _ in range(8):
-            trainer.step()
-        el, _, _ = timed_loop(trainer, eng, fence, 2)
-        per_batch = all_max(el) / 2.0
-        calibration = 10
-        bps = int(min(256, max(1, math.ceil(args.min_seconds / max(args.steps, 1) / max(per_batch, 1e-6)))))
-    for _ in range(args.warmup * bps):
-        trainer.step()
-    if saved_stdout is not None:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1); os.close(saved_stdout)
-    failed_before = trainer.failed_episodes()
-    elapsed, kernel_ms, n_launch = timed_loop(trainer, eng, fence, args.steps * bps)
-    elapsed = all_max(elapsed)
-    failed = trainer.failed_episodes() - failed_before      # episodes of ALL ranks that did not finish (counted by the updates)
-    had_best = True      # (a best strategy exists from the first batch on)
-    last_first = (trainer.step_index - 1) * args.episodes * world_size + rank * args.episodes
-    census = batch_census(eng, args.episodes, last_first, trainer.replay_period, had_best)
-    trainer.sync()                     # device-resident policy -> host copy (after the timed region)
-    avg_kernel_s = kernel_ms / max(n_launch, 1) * 1e-3
+    def measure(tr, w, after_warmup=None):
+        """Calibration (untimed for the result: the last 2 passes of 10 size `batches_per_step`), W warm-up steps, K timed steps,
+        then what the last batch did."""
+        replay = {"best_list_len": int(sum(len(l) for l in w.lists(0))), "best_deficit_list_len": int(sum(len(l) for l in w.lists(1)))}      # (as pushed)
+        bps = args.batches_per_step
+        calibration = 0
+        if bps <= 0:
+            for _ in range(8):
+                tr.step()
+            el, _, _ = timed_loop(tr, eng, fence, 2)
+            calibration = 10
+            bps = int(min(256, max(1, math.ceil(args.min_seconds / max(args.steps, 1) / max(all_max(el) / 2.0, 1e-6)))))
+        for _ in range(args.warmup * bps):
+            tr.step()
+        if after_warmup:
+            after_warmup()
+        failed_before = tr.failed_episodes()
+        elapsed, kernel_ms, n_launch = timed_loop(tr, eng, fence, args.steps * bps)
+        elapsed = all_max(elapsed)
+        failed = tr.failed_episodes() - failed_before      # episodes of ALL ranks that did not finish (counted by the updates)
+        last_first = (tr.step_index - 1) * args.episodes * tr.ws + tr.rank * args.episodes
+        census = batch_census(eng, args.episodes, last_first, tr.replay_period, True)      # (a best strategy exists from the first batch on)
+        tr.sync()                     # device-resident policy -> host copy (after the timed region)
+        batches = args.steps * bps
+        return {"bps": bps, "calibration": calibration, "elapsed": elapsed, "batches": batches, "failed": failed, "census": census,
+                "avg_kernel_s": kernel_ms / max(n_launch, 1) * 1e-3, "value": (args.episodes * tr.ws * batches - failed) / elapsed,
+                "replay": replay}
+
+    def policy_text(grown: bool) -> str:
+        if args.trajectory:
+            return "free-running: every batch builds on the update of the one before (--trajectory)"
+        start = (f"the policy the single-GPU training loop holds {GROW_BATCHES} batches after the seeded one (replay episodes have won and "
+                 "doubled the replayed list, SURVEY Q15)") if grown else \
+                "the seeded policy (ActionWeights::new + config 1's episode as the best strategy, SURVEY §8(d) config 3)"
+        return (f"pinned: every batch starts from {start}, put back by eg_policy_rewind (a device-to-device copy inside the timed region); "
+                "the batch's update runs in full and is not carried into the next batch — the same work per batch on any number of GPUs")
+
+    def restore_stdout():
+        nonlocal saved_stdout
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1); os.close(saved_stdout)
+            saved_stdout = None
+
+    m = measure(trainer, weights, restore_stdout)
+    wkey = workload_key(args.episodes, args.replay_fraction) + ("grown" if args.grown and args.replay_fraction > 0.0 else "") \
+        + ("traj" if args.trajectory else "")
 
     line = None
     if rank == 0:
-        batches = args.steps * bps
-        total_eps = args.episodes * world_size * batches - failed
+        census = m["census"]
         cfg_name = ("BASELINE configs[2]" if world_size == 1 else f"BASELINE configs[3] at {world_size} GPUs") \
             if (args.episodes == 16384 and abs(args.replay_fraction - 0.1) < 1e-12) else \
             ("BASELINE configs[1]" if (args.episodes == 1024 and args.replay_fraction == 0.0 and world_size == 1) else "custom")
         line = {
-            "metric": "26-year episodes/sec", "value": total_eps / elapsed, "unit": "episodes/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "26-year episodes/sec", "value": m["value"], "unit": "episodes/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "batches_per_step": bps, "ms_per_batch": elapsed / batches * 1e3, "timed_region_s": elapsed, "calibration_batches": calibration,
+            "batches_per_step": m["bps"], "ms_per_batch": m["elapsed"] / m["batches"] * 1e3, "timed_region_s": m["elapsed"],
+            "calibration_batches": m["calibration"],
             "config": {"workload": f"{cfg_name}: {args.episodes} parallel 2025-2050 episodes per GPU per batch"
                                    + (f", every {trainer.replay_period}th global index replaying the best strategy (experience replay, reference "
                                       "semantics incl. its double recording, SURVEY Q15)" if trainer.replay_period else ", no replay")
                                    + "; batch pass = rollout (grid step + tabular policy sampling) + batch policy update on the device; synthetic world "
-                                     "S=130 settlements / G0=59 existing plant / P=200 coast points, ActionWeights::new, seed 12345",
+                                     "S=130 settlements / G0=59 existing plant / P=200 coast points, seed 12345",
                        "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction,
-                       "batches_timed": batches, "episodes_failed": failed,
+                       "batches_timed": m["batches"], "episodes_failed": m["failed"],
                        "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one 32 KB all-gather per update "
                                       "(integer statistics summed in the update kernel)",
                        "last_batch": {k: census[k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
                                                              "generators_per_seeded_episode", "generators_per_replay_episode")},
-                       "replay": {"best_list_len": int(sum(len(l) for l in weights.lists(0))),
-                                  "best_deficit_list_len": int(sum(len(l) for l in weights.lists(1)))},
-                       "strategy_improvements": trainer.improvements,
-                       "iterations_without_improvement": int(weights.get("iterations_without_improvement"))},
-            "roofline": roofline_object(workload_key(args.episodes, args.replay_fraction), census, args.episodes, avg_kernel_s),
+                       "policy": policy_text(args.grown),
+                       "replay": m["replay"],
+                       **({"strategy_improvements": trainer.improvements,
+                           "iterations_without_improvement": int(weights.get("iterations_without_improvement"))} if args.trajectory else {})},
+            "roofline": roofline_object(wkey, census, args.episodes, m["avg_kernel_s"]),
         }
+    # ---- second object (N = 1): the grown-replay state of the same workload — what the training loop turns configs[2] into ----
+    if world_size == 1 and not args.no_config1 and args.replay_fraction > 0.0 and not args.grown and not args.trajectory:
+        wg = seeded_policy(True)
+        tg = BatchTrainer(eng, wg, args.episodes, args.seed, 0, 1, None, replay_fraction=args.replay_fraction,
+                          write_yearly=not args.no_yearly, device_resident=True)
+        tg.pin_policy()
+        g = measure(tg, wg)
+        line["config2_grown"] = {"workload": f"the same batches from the grown-replay state: {policy_text(True)}",
+                                 "value": g["value"], "unit": "episodes/s", "batches_timed": g["batches"], "timed_region_s": g["elapsed"],
+                                 "ms_per_batch": g["elapsed"] / g["batches"] * 1e3, "episodes_failed": g["failed"],
+                                 "last_batch": {k: g["census"][k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
+                                                                            "generators_per_seeded_episode", "generators_per_replay_episode")},
+                                 "replay": g["replay"],
+                                 "roofline": roofline_object(workload_key(args.episodes, args.replay_fraction) + "grown", g["census"],
+                                                             args.episodes, g["avg_kernel_s"])}
     # ---- second object: BASELINE configs[1] (1024 episodes per batch, no replay), its own policy and timed region ----
     if world_size == 1 and not args.no_config1 and not (args.episodes == 1024 and args.replay_fraction == 0.0):
         w1 = ActionWeights()
-        t1 = BatchTrainer(eng, w1, 1024, args.seed, 0, 1, None, replay_fraction=0.0, write_yearly=not args.no_yearly)
+        t1 = BatchTrainer(eng, w1, 1024, args.seed, 0, 1, None, replay_fraction=0.0, write_yearly=not args.no_yearly, device_resident=True)
+        if not args.trajectory:
+            t1.pin_policy()
         for _ in range(8):
             t1.step()
         el, _, _ = timed_loop(t1, eng, fence, 8)
@@ -363,7 +432,8 @@ def main():
         f1 = t1.failed_episodes() - f0
         c1 = batch_census(eng, 1024, (t1.step_index - 1) * 1024, 0, True)
         t1.sync()
-        line["config1"] = {"workload": "BASELINE configs[1]: 1024 parallel episodes per batch, no replay; batch pass = rollout + batch policy update",
+        line["config1"] = {"workload": "BASELINE configs[1]: 1024 parallel episodes per batch, no replay; batch pass = rollout + batch policy update; "
+                                       + ("free-running policy" if args.trajectory else "every batch from ActionWeights::new (pinned like the headline)"),
                            "value": (1024 * n1 - f1) / el, "unit": "episodes/s", "batches_timed": n1, "timed_region_s": el,
                            "ms_per_batch": el / n1 * 1e3, "episodes_failed": f1,
                            "roofline": roofline_object(workload_key(1024, 0.0), c1, 1024, kms / max(nl, 1) * 1e-3)}

@@ -59,6 +59,7 @@ struct eg_ctx {
   // snapshot in HBM
   // the whole snapshot lives in ONE device buffer filled by ONE copy from a pinned staging buffer
   uint8_t* d_snap = nullptr; uint8_t* h_snap = nullptr;
+  uint8_t* d_snap_held = nullptr;      // eg_policy_hold / eg_policy_rewind
   DevSnapshot snap{};
   bool snap_valid = false;
   // outputs
@@ -87,6 +88,7 @@ struct eg_ctx {
   uint32_t helper_max_episodes = 0;
   // heavy episodes (eg_rollout.hip place_heavy): pool of penalty fields, one slot per episode that outgrows kHeavyGens
   uint32_t heavy_slots_wanted = 4096, launch_epoch = 0;
+  bool heavy_slots_auto = true;      // (EIRGRID_HEAVY_SLOTS fixes the pool size instead)
 };
 
 namespace {
@@ -132,20 +134,35 @@ int collect_timing(eg_ctx* c, int count = -1) {
   }
   return EG_OK;
 }
-// before every rollout launch: the field pool exists (allocated on first use) and the launch has an epoch of its own
-int prepare_heavy(eg_ctx* c) {
+// before every rollout launch: the field pool holds a slot for every heavy episode of the launch (allocated on first use,
+// enlarged when a launch brings more of them: a replay episode without a slot falls back to the exact scan, 20-40x slower,
+// and a launch lasts as long as its slowest episode) and the launch has an epoch of its own
+int prepare_heavy(eg_ctx* c, uint32_t n_heavy) {
   constexpr size_t kSlotBytes = size_t(kRadiusClasses) * 2624 * sizeof(double);
-  if (!c->dev.heavy && c->heavy_slots_wanted > 0) {
-    void* pool = nullptr; void* claim = nullptr;
-    if (hipMalloc(&pool, kSlotBytes * c->heavy_slots_wanted) != hipSuccess || hipMalloc(&claim, 64) != hipSuccess) {
-      (void)hipGetLastError();
-      if (pool) (void)hipFree(pool);
-      c->heavy_slots_wanted = 0;      // no memory for it: heavy episodes take the exact scan
-    } else {
-      EG_HIP(hipMemset(claim, 0xFF, 64));      // an epoch no launch uses
-      c->allocs.push_back(pool); c->allocs.push_back(claim);
-      c->dev.heavy = static_cast<uint8_t*>(pool); c->dev.heavy_claim = static_cast<unsigned*>(claim); c->dev.heavy_slots = c->heavy_slots_wanted;
+  uint32_t want = c->heavy_slots_wanted;
+  if (c->heavy_slots_auto && want > 0) {      // 4 096 slots (516 MB) to begin with, then the next power of two, at most 1 M slots = 126 GB
+    while (want < n_heavy && want < (1u << 20) - 1u) want = want * 2u < (1u << 20) ? want * 2u : (1u << 20) - 1u;
+  }
+  if (want > 0 && n_heavy > 0 && (!c->dev.heavy || want > c->dev.heavy_slots)) {
+    void* pool = nullptr;
+    if (c->dev.heavy) {      // earlier launches may still use the old pool
+      EG_HIP(hipDeviceSynchronize());
+      for (auto it = c->allocs.begin(); it != c->allocs.end(); ++it) if (*it == c->dev.heavy) { c->allocs.erase(it); break; }
+      (void)hipFree(c->dev.heavy);
+      c->dev.heavy = nullptr; c->dev.heavy_slots = 0;
     }
+    if (!c->dev.heavy_claim) {
+      void* claim = nullptr;
+      if (hipMalloc(&claim, 64) != hipSuccess) { (void)hipGetLastError(); c->heavy_slots_wanted = 0; want = 0; }
+      else { EG_HIP(hipMemset(claim, 0xFF, 64)); c->allocs.push_back(claim); c->dev.heavy_claim = static_cast<unsigned*>(claim); }      // 0xFF..: an epoch no launch uses
+    }
+    while (want > 0 && hipMalloc(&pool, kSlotBytes * want) != hipSuccess) {      // no memory for that many: fewer; none: heavy episodes take the exact scan
+      (void)hipGetLastError();
+      pool = nullptr;
+      want = want > 4096u ? want / 2u : 0u;
+      c->heavy_slots_auto = false; c->heavy_slots_wanted = want;
+    }
+    if (pool) { c->allocs.push_back(pool); c->dev.heavy = static_cast<uint8_t*>(pool); c->dev.heavy_slots = want; }
   }
   c->launch_epoch = (c->launch_epoch + 1u) & 0xFFFu;
   if (c->launch_epoch == 0xFFFu) c->launch_epoch = 0u;      // 0xFFF is the "never" epoch the claim word starts with
@@ -189,7 +206,7 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   const bool split = plan.n_heavy > 0 && plan.n_lean > 0;
   plan.stream_heavy = split ? c->stream_heavy : nullptr;
   plan.stream_lean = split ? c->stream_lean : nullptr;
-  int rc = prepare_heavy(c);
+  int rc = prepare_heavy(c, plan.n_heavy);
   if (rc != EG_OK) return rc;
   const int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, period, d_stats, plan);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -224,8 +241,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) != hipSuccess) cus = 0;
     c->helper_max_episodes = 4u * (uint32_t)(cus > 0 ? cus : 0);
-    // EIRGRID_HEAVY_SLOTS: field slots for heavy episodes (default 4096 = 516 MB; 0 = every search is the exact scan)
-    if (const char* hs = std::getenv("EIRGRID_HEAVY_SLOTS")) c->heavy_slots_wanted = (uint32_t)std::strtoul(hs, nullptr, 10);
+    // EIRGRID_HEAVY_SLOTS: a fixed number of field slots for heavy episodes (default: 4096 = 516 MB, enlarged to what a launch needs;
+    // 0 = every search is the exact scan)
+    if (const char* hs = std::getenv("EIRGRID_HEAVY_SLOTS")) { c->heavy_slots_wanted = (uint32_t)std::strtoul(hs, nullptr, 10); c->heavy_slots_auto = false; }
     if (c->heavy_slots_wanted > (1u << 20) - 1u) c->heavy_slots_wanted = (1u << 20) - 1u;
     if (const char* hv = std::getenv("EIRGRID_HELPER_WAVES")) {
       if (std::string(hv) == "0") c->helper_max_episodes = 0;
@@ -328,6 +346,7 @@ void eg_destroy(eg_ctx* c) {
   (void)hipDeviceSynchronize();
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->d_snap) (void)hipFree(c->d_snap);
+  if (c->d_snap_held) (void)hipFree(c->d_snap_held);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_packet) (void)hipFree(c->d_packet);
@@ -638,6 +657,22 @@ int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_ow
   return EG_OK;
 }
 }  // namespace
+
+int32_t eg_policy_hold(eg_ctx* c) {
+  if (!c || !c->snap_valid) { set_error("eg_policy_hold: push a policy first"); return EG_ERR_BAD_ARG; }
+  if (!c->d_snap_held) EG_HIP(hipMalloc((void**)&c->d_snap_held, snap::total));
+  EG_HIP(hipMemcpyAsync(c->d_snap_held, c->d_snap, snap::total, hipMemcpyDeviceToDevice, nullptr));
+  return EG_OK;
+}
+
+int32_t eg_policy_rewind(eg_ctx* c) {
+  if (!c || !c->d_snap_held) { set_error("eg_policy_rewind: nothing held"); return EG_ERR_BAD_ARG; }
+  // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting)
+  constexpr size_t failed = snap::state + offsetof(DevState, failed_total);
+  EG_HIP(hipMemcpyAsync(c->d_snap_held + failed, c->d_snap + failed, sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+  EG_HIP(hipMemcpyAsync(c->d_snap, c->d_snap_held, snap::total, hipMemcpyDeviceToDevice, nullptr));
+  return EG_OK;
+}
 
 int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
   if (!c || !p || !c->snap_valid) { set_error("eg_policy_pull: push a policy first"); return EG_ERR_BAD_ARG; }

@@ -1406,13 +1406,28 @@ __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b)
 
 // (the heavy variant trades occupancy for registers: two waves per SIMD, 256 VGPRs — its grid is the few long episodes,
 //  which are bound by their own serial latency, and the field code inlines without spilling)
-template <int kHelpers, bool kHeavy>
-__global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
+// kKind: kLean = sampled episodes only (no replay code at all); kReplayShort / kReplayLong = the episodes that replay the best
+// strategy, on the lean kernel's budget while the replayed list is short and on the heavy-capable variant once it is long.
+// Both are launched over the replay episodes of a batch and the one whose turn it is not returns at once: how long the list
+// is only the device knows (an on-device update may have replaced it since the host last looked), and the host plans
+// launches many batches ahead of the device.
+constexpr int kLean = 0, kReplayShort = 1, kReplayLong = 2;
+// actions in the best list up to which replay episodes stay on the exact scan (measured at 16 384 x 10 %: a batch with an
+// 82-action list — 90 generators per replay episode — takes 2.02 ms this side of the limit and 2.37 ms on the other, one
+// with a 109-action list — 117 generators — 2.39 against 2.25)
+constexpr int kShortReplayMax = 96;
+template <int kHelpers, int kKind>
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? 2 : 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
                                                                     const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
                                                                     long long* stats, EpisodeMap emap) {
+  constexpr bool kHeavy = kKind == kReplayLong, kReplay = kKind != kLean;
   const int lane = threadIdx.x & (kWave - 1);
   if (blockIdx.x >= emap.count) return;
+  if constexpr (kReplay) {      // (uniform for the whole grid)
+    const bool long_list = S_in.state()->has_lists && S_in.best_off()[EG_YEARS] > kShortReplayMax;
+    if (long_list != kHeavy) return;
+  }
   const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
   uint32_t search_seq = 0, year_seq = 0;      // commands to the helper wave share one sequence
@@ -1436,7 +1451,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
   // the device (the host cannot know whether a best strategy exists yet), from a period over the global episode index
   // (Replay episodes always run the heavy-capable variant — the launch plan sends them there, eg_api.cpp launch_batch —, so
   //  the lean variant carries no replay code at all.)
-  const bool replay = kHeavy && (replay_mask != nullptr ? replay_mask[e] != 0
+  const bool replay = kReplay && (replay_mask != nullptr ? replay_mask[e] != 0
                                                         : (replay_period != 0u && S.has_best_actions && (first_index + e) % replay_period == 0ull));
   const int n_existing = T.n_existing;
 #ifdef EG_STAMPS
@@ -1537,7 +1552,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kHeavy ? 2 : 3) k_roll
     // a replay episode reads this year's lists once: offsets as scalars, the first 128 / 64 entries one per lane (an action is
     // then a v_readlane instead of two dependent global round trips per action)
     int rep_lo = 0, rep_n = 0, repd_lo = 0, repd_n = 0, rep0 = 0, rep1 = 0, repd0 = 0;
-    if constexpr (kHeavy) if (replay) {
+    if constexpr (kReplay) if (replay) {
       rep_lo = __builtin_amdgcn_readfirstlane(S.best_off()[yi]); rep_n = __builtin_amdgcn_readfirstlane(S.best_off()[yi + 1]) - rep_lo;
       repd_lo = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi]); repd_n = __builtin_amdgcn_readfirstlane(S.bestd_off()[yi + 1]) - repd_lo;
       if (!S.has_best_actions) rep_n = 0;
@@ -2278,16 +2293,16 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 }  // namespace
 
 namespace {
-template <bool kHeavy>
+template <int kKind>
 void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                     const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const EpisodeMap& map, void* stream, void* ev0, void* ev1) {
   // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
   if (helper_waves)
-    hipExtLaunchKernelGGL((k_rollout<kHelperWaves, kHeavy>), dim3(map.count), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
+    hipExtLaunchKernelGGL((k_rollout<kHelperWaves, kKind>), dim3(map.count), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
                           (hipEvent_t)ev0, (hipEvent_t)ev1, 0, t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n,
                           d_replay_mask, replay_period, d_stats, map);
   else
-    hipExtLaunchKernelGGL((k_rollout<0, kHeavy>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
+    hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
                           t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map);
 }
 }  // namespace
@@ -2295,13 +2310,17 @@ void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s,
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& p) {
   if (n == 0) return 0;
-  if (p.n_heavy > 0) {      // first, so that the long episodes start first
+  if (p.n_heavy > 0) {      // first, so that the long episodes start first: both replay variants, one of which returns at once
     EpisodeMap m{};
     m.count = p.n_heavy;
     if (p.n_lean == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index; }
     else { m.mode = 2u; m.off = p.off; m.period = p.period; }
-    launch_variant<true>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, p.ev[0], p.ev[1]);
+    // (the short one first: when it is the one that returns at once it finds the chip empty and is gone in microseconds; a
+    //  256-register wave of the long one, when IT has nothing to do, must wait until a SIMD full of lean waves has drained two
+    //  of them, and whatever is queued behind it on the stream waits with it — measured: 0.6 ms)
+    launch_variant<kReplayShort>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, p.ev[0], nullptr);
+    launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, p.ev[1]);
   }
   if (p.n_lean > 0) {
     EpisodeMap m{};
@@ -2309,7 +2328,7 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     if (p.n_heavy == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index + p.n_heavy; }
     else { m.mode = 3u; m.off = p.off; m.period = p.period; }
-    launch_variant<false>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_lean, p.ev[2], p.ev[3]);
+    launch_variant<kLean>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_lean, p.ev[2], p.ev[3]);
   }
   return (int)hipGetLastError();
 }

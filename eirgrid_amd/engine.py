@@ -343,6 +343,14 @@ class Engine:
         N.check(N.lib().eg_device_step(self.h, C.c_uint64(seed & (2**64 - 1)), C.c_uint64(first_episode_index), n_episodes,
                                        replay_period, C.c_uint64(noise_seed & (2**64 - 1))), "eg_device_step")
 
+    def hold(self):
+        """Keep a device-side copy of the device-resident policy (eg_policy_hold)."""
+        N.check(N.lib().eg_policy_hold(self.h), "eg_policy_hold")
+
+    def rewind(self):
+        """Put the held copy back (eg_policy_rewind)."""
+        N.check(N.lib().eg_policy_rewind(self.h), "eg_policy_rewind")
+
     def pull(self, weights: ActionWeights):
         N.check(N.lib().eg_policy_pull(self.h, weights.h), "eg_policy_pull")
 

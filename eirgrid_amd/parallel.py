@@ -151,6 +151,7 @@ class BatchTrainer:
         self.replay_period = max(1, int(round(1.0 / replay_fraction))) if replay_fraction > 0.0 else 0
         self.write_yearly = write_yearly
         self.step_index = 0
+        self.pinned = False
         # force_collectives: run the all-gather even with one rank (exercises the RCCL path on one GPU)
         multi = dist is not None and (world_size > 1 or force_collectives)
         self.multi = multi
@@ -177,6 +178,15 @@ class BatchTrainer:
         self.sync()
         return int(self.w.get("failed_episodes"))
 
+    def pin_policy(self):
+        """From now on every step starts from the policy as it is on the device at this moment (eg_policy_hold / eg_policy_rewind):
+        the update of a step runs in full, the next step does not build on it.  bench.py measures that way: every batch is
+        then the same work on any number of GPUs, where the free-running loop changes what a replay episode costs (Q15)."""
+        if not self.device_resident:
+            raise RuntimeError("pin_policy needs the device-resident mode")
+        self.eng.hold()
+        self.pinned = True
+
     def sync(self):
         """Wait for the enqueued steps and bring `weights` up to date (device-resident mode)."""
         if self.device_resident:
@@ -192,6 +202,8 @@ class BatchTrainer:
         noise = self.seed + self.step_index
         nstat = 8 * N.STATS_LEN
         if self.device_resident:
+            if self.pinned:
+                self.eng.rewind()
             if not self.multi:
                 self.eng.device_step(self.seed, first, self.n, self.replay_period, noise)
             else:

@@ -282,6 +282,12 @@ int32_t eg_device_apply(eg_ctx *, const void *d_packets, int32_t n_packets, void
 int32_t eg_device_step(eg_ctx *, uint64_t seed, uint64_t first_episode_index, uint32_t n_episodes, uint32_t replay_period,
                        uint64_t noise_seed);
 int32_t eg_policy_pull(eg_ctx *, eg_policy *);
+/* Measurement support (no counterpart in the reference): eg_policy_hold keeps a copy of the device-resident policy as it is
+ * now — tables, best strategy, counters — on the device, stream-ordered; eg_policy_rewind puts that copy back.  bench.py
+ * rewinds before every batch, so that every batch is the same work on any number of GPUs: left to itself the training loop
+ * changes what a replay episode costs, differently for every global batch size. */
+int32_t eg_policy_hold(eg_ctx *);
+int32_t eg_policy_rewind(eg_ctx *);
 /* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */

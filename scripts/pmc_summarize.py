@@ -2,11 +2,13 @@
 
   python scripts/pmc_summarize.py <tag> <out_dir> <workload>:<fetch_dir>:<write_dir> [...]
 
-Each dir is the -d directory of one counter pass of `python3 bench.py --steps 4 --warmup 20 --no-cpu-baseline --batches-per-step 2 ...` of that
-workload ("16384r0.1" = BASELINE configs[2], the default; "1024" = configs[1]).  A batch with replay episodes is two
-k_rollout grids (the heavy-capable variant `k_rollout<.., true>` for the replays, the lean one for the rest); the counters
-of a batch are the sum of its grids.  Only the dispatches of the TIMED region (the last steps x batches_per_step = 8 per
-variant) are averaged, after 40 warm-up batches: the loop's cost per batch changes while the first best strategies are found.
+Each dir is the -d directory of one counter pass of `python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --batches-per-step 2 ...` of that
+workload ("16384r0.1" = BASELINE configs[2], the default; "16384r0.1grown" = the same from the grown-replay state, --grown;
+"1024" = configs[1]).  A batch with replay episodes is two
+k_rollout grids for the replays (`k_rollout<.., 2>`, the heavy-capable variant, and `k_rollout<.., 1>`, the short-replay one:
+whichever the length of the best list does not call for returns at once) and the lean one (`k_rollout<.., 0>`) for the rest; the
+counters of a batch are the sum of its grids.  Only the dispatches of the TIMED region (the last steps x batches_per_step = 8 per
+variant) are averaged (every batch starts from the same policy, so they are all alike).
 HBM bytes per batch = 2 * FETCH_SIZE * 1024 (gfx950: FETCH_SIZE counts half of a wide stream, MI355X_MICROARCH.md HBM
 section; an upper bound for narrow gathers) + WRITE_SIZE * 1024.  Counter collection serialises the dispatches, so
 `kernel_ns` (heavy + lean, one after the other) is longer than the overlapped launch of an un-profiled run.
@@ -16,13 +18,13 @@ import csv, glob, json, os, sys
 TIMED = 8
 
 
-def variant_of(name):
+def variant_of(name):      # k_rollout<helpers, kind>: kind 2 = long-replay (heavy-capable) variant, 1 = short-replay, 0 = lean
     if "k_rollout" not in name: return None
-    return "heavy" if ", true>" in name else "lean"
+    return "heavy" if ", 2>" in name else ("short" if ", 1>" in name else "lean")
 
 
 def rows(d, counter):
-    out = {"heavy": [], "lean": []}
+    out = {"heavy": [], "short": [], "lean": []}
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             v = variant_of(r["Kernel_Name"])
@@ -47,13 +49,13 @@ def main():
     for spec in specs:
         wl, fd, wd = spec.split(":")
         f, w = rows(fd, "FETCH_SIZE"), rows(wd, "WRITE_SIZE")
-        if not f["lean"] and not f["heavy"]:
+        if not f["lean"] and not f["heavy"] and not f["short"]:
             raise SystemExit(f"no k_rollout rows under {fd}")
-        fa = avg(f["heavy"], "value_kb") + avg(f["lean"], "value_kb"); wa = avg(w["heavy"], "value_kb") + avg(w["lean"], "value_kb")
-        doc["configs"][wl] = dict(workload=wl, launches=max(len(f["lean"]), len(f["heavy"])), fetch_size_kb_avg=fa, write_size_kb_avg=wa,
+        fa = sum(avg(f[v], "value_kb") for v in f); wa = sum(avg(w[v], "value_kb") for v in w)
+        doc["configs"][wl] = dict(workload=wl, launches=max(len(f[v]) for v in f), fetch_size_kb_avg=fa, write_size_kb_avg=wa,
                                   hbm_bytes_per_launch=2 * fa * 1024 + wa * 1024,
-                                  kernel_ns=avg(f["heavy"], "dur_ns") + avg(f["lean"], "dur_ns"),
-                                  kernel_ns_heavy=avg(f["heavy"], "dur_ns"), kernel_ns_lean=avg(f["lean"], "dur_ns"),
+                                  kernel_ns=sum(avg(f[v], "dur_ns") for v in f),
+                                  kernel_ns_heavy=avg(f["heavy"], "dur_ns"), kernel_ns_short=avg(f["short"], "dur_ns"), kernel_ns_lean=avg(f["lean"], "dur_ns"),
                                   fetch_rows=f, write_rows=w)
     path = os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.json")
     json.dump(doc, open(path, "w"), indent=1)

@@ -229,6 +229,49 @@ def test_device_resident_training_equals_host_updates(engine, world):
         dev.close()
 
 
+def test_hold_and_rewind_put_the_device_policy_back(world):
+    """eg_policy_hold / eg_policy_rewind (what bench.py does before every batch): after a rewind the device-resident policy is
+    the held one — tables, best strategy, counters — so the same step gives the same bytes again; only the count of failed
+    episodes goes on counting."""
+    from eirgrid_amd.engine import Engine
+    dev = Engine(world, device=0)
+    names = ("iterations_without_improvement", "iteration_count", "has_best", "best_cost", "best_net_emissions", "best_opinion",
+             "best_reliability", "has_best_actions", "has_best_deficit_actions", "learning_rate", "exploration_rate")
+
+    def state(p):
+        return ([t.tobytes() for t in p.tables()], p.lists(0), p.lists(1), [p.get(k) for k in names])
+    try:
+        pol = ActionWeights()
+        first = dev.run_iteration(0, pol, False, 12345)
+        pol.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
+                          first.def_log[0, :first.n_def[0].sum()])
+        dev.push(pol)
+        for k in range(3):      # not the pushed state itself: one that on-device updates have produced
+            dev.device_step(77, k * 512, 512, 4, 500 + k)
+        dev.hold()
+        dev.pull(pol); held = state(pol)
+        dev.device_step(77, 4096, 512, 4, 600)
+        a = dev.fetch(512)
+        dev.pull(pol); moved = state(pol)
+        assert moved != held
+        for k in range(4):
+            dev.device_step(77, 8192 + k * 512, 512, 4, 700 + k)
+        dev.rewind()
+        dev.pull(pol)
+        assert state(pol) == held
+        dev.device_step(77, 4096, 512, 4, 600)
+        b = dev.fetch(512)
+        dev.pull(pol)
+        assert state(pol) == moved
+        for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_gens"):
+            assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
+        for name, count in (("run_log", a.n_run.sum(axis=1)), ("def_log", a.n_def.sum(axis=1)), ("gen_cell", a.n_gens)):      # (the buffers are not cleared between batches)
+            live = np.arange(getattr(a, name).shape[1])[None, :] < count[:, None]
+            assert (getattr(a, name)[live] == getattr(b, name)[live]).all(), name
+    finally:
+        dev.close()
+
+
 def test_rccl_path_of_the_trainer_on_one_rank():
     """The N > 1 device-resident step (eg_device_rollout -> all_reduce -> all_gather_into_tensor -> eg_device_apply, all
     on the stream) with the collectives really issued through RCCL (world size 1, forced) == the single-GPU step."""
