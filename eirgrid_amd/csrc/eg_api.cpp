@@ -72,7 +72,8 @@ struct eg_ctx {
   static constexpr int kTimingRing = 256;
   hipEvent_t ev[kTimingRing][4] = {};       // start / stop of the heavy grid, start / stop of the lean grid (eg_internal.h RolloutPlan)
   uint8_t ev_used[kTimingRing] = {};        // bit 0: the heavy pair was recorded, bit 1: the lean pair
-  hipStream_t stream_heavy = nullptr, stream_lean = nullptr;   // the two grids of a split batch run side by side
+  hipStream_t stream_heavy = nullptr;   // the replay grids of a split batch run beside the lean grid (which stays on the null stream)
+  hipEvent_t ev_fork[kTimingRing] = {}, ev_join[kTimingRing] = {};
   uint32_t* d_index = nullptr; uint32_t index_cap = 0;         // replay / other episode indices of a host-masked batch
   int ring_head = 0, ring_pending = 0;      // next pair to use; pairs recorded and not yet collected (the oldest is head - pending)
   double total_ms = 0.0; int32_t n_launches = 0;
@@ -107,9 +108,10 @@ void free_outputs(eg_ctx* c) {
 int ensure_outputs(eg_ctx* c, uint32_t n) {
   if (n <= c->out_cap) return EG_OK;
   free_outputs(c);
-  EG_HIP(hipMalloc((void**)&c->out.base, size_t(n) * rec::stride));
+  EG_HIP(hipMalloc((void**)&c->out.base, size_t(n) * rec::stride + size_t(n) * sizeof(double)));
+  c->out.score_list = reinterpret_cast<double*>(c->out.base + size_t(n) * rec::stride);
   // zero once so episodes that end early leave defined year counts / rows behind
-  EG_HIP(hipMemset(c->out.base, 0, size_t(n) * rec::stride));
+  EG_HIP(hipMemset(c->out.base, 0, size_t(n) * rec::stride + size_t(n) * sizeof(double)));
   c->out_cap = n;
   return EG_OK;
 }
@@ -201,15 +203,25 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   if (c->ring_pending == eg_ctx::kTimingRing) { int rc = collect_timing(c, 1); if (rc != EG_OK) return rc; }
   const int slot = c->ring_head;
   for (int k = 0; k < 4; ++k) plan.ev[k] = c->ev[slot][k];
-  // a batch that is one grid stays on the null stream like every other kernel of the library; two grids go to two streams
-  // of their own (blocking streams: they wait for earlier null-stream work, later null-stream work waits for them)
+  // A batch that is one kind of grid stays on the null stream like every other kernel of the library.  With both kinds the lean
+  // grid still does; the replay grids go to a (non-blocking) stream of their own that forks off the null stream before them and
+  // joins it after the lean grid's launch — two explicit events.  (They were two blocking streams at first: the implicit
+  // null-stream synchronisation of those cost 30 us before the grids and 16 us after them, every batch.)
   const bool split = plan.n_heavy > 0 && plan.n_lean > 0;
   plan.stream_heavy = split ? c->stream_heavy : nullptr;
-  plan.stream_lean = split ? c->stream_lean : nullptr;
+  plan.stream_lean = nullptr;
   int rc = prepare_heavy(c, plan.n_heavy);
   if (rc != EG_OK) return rc;
+  if (split) {
+    EG_HIP(hipEventRecord(c->ev_fork[slot], nullptr));
+    EG_HIP(hipStreamWaitEvent(c->stream_heavy, c->ev_fork[slot], 0));
+  }
   const int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, period, d_stats, plan);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  if (split) {
+    EG_HIP(hipEventRecord(c->ev_join[slot], c->stream_heavy));
+    EG_HIP(hipStreamWaitEvent(nullptr, c->ev_join[slot], 0));
+  }
   c->ev_used[slot] = uint8_t((plan.n_heavy > 0 ? 1 : 0) | (plan.n_lean > 0 ? 2 : 0));
   c->ring_head = (c->ring_head + 1) % eg_ctx::kTimingRing; c->ring_pending += 1;
   c->last_n = n; c->last_first = first_index;
@@ -330,7 +342,11 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
     for (int k = 0; k < 4; ++k)
       if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; break; }
-  if (rc == EG_OK && (hipStreamCreate(&c->stream_heavy) != hipSuccess || hipStreamCreate(&c->stream_lean) != hipSuccess)) { set_error("hipStreamCreate failed"); rc = EG_ERR_HIP; }
+  if (rc == EG_OK && hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = EG_ERR_HIP; }
+  for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
+    if (hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) {
+      set_error("hipEventCreate failed"); rc = EG_ERR_HIP;
+    }
   if (rc == EG_OK) {
     if (hipMalloc((void**)&c->d_snap, snap::total) != hipSuccess || hipHostMalloc((void**)&c->h_snap, snap::total) != hipSuccess) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
@@ -355,7 +371,7 @@ void eg_destroy(eg_ctx* c) {
   for (int i = 0; i < eg_ctx::kTimingRing; ++i)
     for (int k = 0; k < 4; ++k) if (c->ev[i][k]) (void)hipEventDestroy(c->ev[i][k]);
   if (c->stream_heavy) (void)hipStreamDestroy(c->stream_heavy);
-  if (c->stream_lean) (void)hipStreamDestroy(c->stream_lean);
+  for (int i = 0; i < eg_ctx::kTimingRing; ++i) { if (c->ev_fork[i]) (void)hipEventDestroy(c->ev_fork[i]); if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]); }
   if (c->d_index) (void)hipFree(c->d_index);
   if (c->d_place_cells) (void)hipFree(c->d_place_cells);
   if (c->d_place_cell) (void)hipFree(c->d_place_cell);
@@ -667,10 +683,9 @@ int32_t eg_policy_hold(eg_ctx* c) {
 
 int32_t eg_policy_rewind(eg_ctx* c) {
   if (!c || !c->d_snap_held) { set_error("eg_policy_rewind: nothing held"); return EG_ERR_BAD_ARG; }
-  // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting)
-  constexpr size_t failed = snap::state + offsetof(DevState, failed_total);
-  EG_HIP(hipMemcpyAsync(c->d_snap_held + failed, c->d_snap + failed, sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
-  EG_HIP(hipMemcpyAsync(c->d_snap, c->d_snap_held, snap::total, hipMemcpyDeviceToDevice, nullptr));
+  // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting; one small kernel instead of two copies)
+  const int lr = launch_rewind(c->d_snap, c->d_snap_held, nullptr);
+  if (lr != 0) { set_error(std::string("k_rewind launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
 

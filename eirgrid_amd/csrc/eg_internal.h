@@ -221,6 +221,7 @@ namespace snap { constexpr size_t total = best_rec + rec::stride; }
 
 struct DevOut {
   uint8_t* base;
+  double* score_list;      // the episodes' scores once more, back to back (the update's best pick reads all of them: one per 12 KB record is one cache line each)
 #define EG_REC(name, type) EG_HD type* name(uint32_t e) const { return reinterpret_cast<type*>(base + size_t(e) * rec::stride + rec::name); }
   EG_REC(metrics, double) EG_REC(score, double) EG_REC(bytes_moved, double) EG_REC(n_draws, unsigned long long)
   EG_REC(status, int32_t) EG_REC(n_gens, int32_t) EG_REC(n_offsets, int32_t) EG_REC(n_chunks, uint32_t)
@@ -251,7 +252,9 @@ struct RolloutPlan {
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& plan);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
-int launch_stalled_tables(uint8_t* d_snap, void* stream);     // no-op on the device unless state.stall > 500
+int launch_stalled_tables(uint8_t* d_snap, void* stream);
+// d_snap = d_held, except the count of failed episodes, which goes on counting (eg_policy_rewind)
+int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, void* stream);     // no-op on the device unless state.stall > 500
 // `o`, n_local, first_index: the batch the own packet came from (the winner's record is kept when it is one of them)
 // local_pick: one packet, made by this device's last batch — the candidate record is built inside the kernel
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,

@@ -1322,13 +1322,13 @@ __device__ __forceinline__ void load_state(DevSnapshot& S) {
 __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats) {
   unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
   if (*O.status(e) != EG_EP_OK) {
-    if (lane == 0) { atomicAdd(&st[1], 1ull); *O.score(e) = -1.0; }
+    if (lane == 0) { atomicAdd(&st[1], 1ull); *O.score(e) = -1.0; O.score_list[e] = -1.0; }
     return;
   }
   const double score = rm::score(O.metrics(e));
   // st[3]: the batch's best score as an integer that sorts like the score (scores are not negative; + 1 so that 0 means
   // "no successful episode"): with one GPU k_apply_update finds the best episode from it without a kernel of its own
-  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
+  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; O.score_list[e] = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
   const bool qualifies = det > P.threshold || P.forced;                                               // learning.rs:160
@@ -1997,7 +1997,7 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
   const int tid = threadIdx.x;
   double best = -1.0; int best_i = -1;
   for (uint32_t i = tid; i < n; i += 1024) {
-    const double sc = *O.score(i);
+    const double sc = O.score_list[i];
     if (sc > best) { best = sc; best_i = (int)i; }      // ascending i per thread: first maximum
   }
   s_score[tid] = best; s_idx[tid] = best_i;
@@ -2043,7 +2043,7 @@ __device__ void chacha12_block(const uint32_t* key, unsigned long long counter, 
 // `packets` = n_packets update packets of EG_PACKET_BYTES (one per rank, in rank order; the gathered copies when N > 1):
 // the statistics are summed here (integers: any order gives the same sum), the candidate records sit behind them.
 __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const uint8_t* packets, int n_cands, long long* zero_stats,
-                                                      unsigned long long noise_seed, const uint8_t* out_base, uint32_t n_local,
+                                                      unsigned long long noise_seed, const uint8_t* out_base, const double* score_list, uint32_t n_local,
                                                       unsigned long long first_index, int local_pick) {
   constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
   constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
@@ -2096,14 +2096,18 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     // The rollout epilogue left the batch's best score in statistics slot 3; the best episode is the lowest index that
     // holds it (highest score, ties to the lowest index), its metrics and lists are copied behind the statistics.
     UpdateCandidate* cw = reinterpret_cast<UpdateCandidate*>(const_cast<uint8_t*>(cands));
-    const DevOut O{const_cast<uint8_t*>(out_base)};
+    const DevOut O{const_cast<uint8_t*>(out_base), const_cast<double*>(score_list)};
     const unsigned long long key = reinterpret_cast<const unsigned long long*>(packets)[3];
     if (tid == 0) s_winner = 0x7FFFFFFF;
     __syncthreads();
-    if (key != 0ull)
-      for (uint32_t i = tid; i < n_local; i += 1024) {
-        const double sc = *O.score(i);
-        if (sc >= 0.0 && (unsigned long long)__double_as_longlong(sc) + 1ull == key) atomicMin(&s_winner, (int)i);
+    if (key != 0ull)      // (from the back-to-back copy of the scores: one per 12 KB record cost 25 us at 16 384 episodes)
+      for (uint32_t base = 0; base < n_local; base += 16u * 1024u) {
+        double sc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t i = base + (uint32_t)k * 1024u + (uint32_t)tid; sc[k] = i < n_local ? O.score_list[i] : -1.0; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (sc[k] >= 0.0 && (unsigned long long)__double_as_longlong(sc[k]) + 1ull == key) atomicMin(&s_winner, (int)(base + (uint32_t)k * 1024u + (uint32_t)tid));
       }
     __syncthreads();
     const int win = s_winner != 0x7FFFFFFF ? s_winner : -1;
@@ -2356,6 +2360,21 @@ int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* st
   hipLaunchKernelGGL(k_fill_lds, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, value, d_sink);
   return (int)hipGetLastError();
 }
+__global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_t* held) {
+  static_assert(snap::total % 16 == 0 && (snap::state + offsetof(DevState, failed_total)) % 4 == 0, "snapshot layout");
+  constexpr uint32_t kFailedWord = (uint32_t)((snap::state + offsetof(DevState, failed_total)) / 4);
+  const uint32_t failed = reinterpret_cast<const uint32_t*>(snap_base)[kFailedWord];
+  __syncthreads();      // (one workgroup: everybody has read the counter before anybody overwrites it)
+  const uint4* src = reinterpret_cast<const uint4*>(held);
+  uint4* dst = reinterpret_cast<uint4*>(snap_base);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(snap::total / 16); i += 256u) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(snap_base)[kFailedWord] = failed;
+}
+int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, void* stream) {
+  hipLaunchKernelGGL(k_rewind, dim3(1), dim3(256), 0, (hipStream_t)stream, d_snap, d_held);
+  return (int)hipGetLastError();
+}
 int launch_stalled_tables(uint8_t* d_snap, void* stream) {
   hipLaunchKernelGGL(k_stalled_tables, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)stream, d_snap);
   return (int)hipGetLastError();
@@ -2363,7 +2382,7 @@ int launch_stalled_tables(uint8_t* d_snap, void* stream) {
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
                         const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream) {
   hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, (const uint8_t*)d_packets, n_packets,
-                     d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, n_local, (unsigned long long)first_index,
+                     d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, (const double*)o.score_list, n_local, (unsigned long long)first_index,
                      local_pick ? 1 : 0);
   return (int)hipGetLastError();
 }
