@@ -18,6 +18,7 @@ constexpr int kMaxReach = 12;   // cells; the largest penalty radius is 12 km
 constexpr int kMults = 3;
 constexpr int kOffsetTypes = 4;
 constexpr int kPsStride = 2624;   // sorted candidate lists on the device: 41 chunks of 64 (2601 -> 2624 entries)
+constexpr int kShortReplayMax = 96;   // actions in the best list up to which replay episodes stay on the exact scan (eg_rollout.hip, k_rollout kinds)
 constexpr int kMaxVariants = 12;  // distinct (radius class, marine) pairs over the 15 types (8 for the reference's types)
 
 // Policy-independent tables, built once per world on the host (eg_tables.cpp) and mirrored in HBM.
@@ -244,6 +245,7 @@ struct UpdateCandidate;
 struct RolloutPlan {
   bool helper_waves;
   void* stream_heavy; void* stream_lean;
+  void* go_event;      // not null: recorded on stream_heavy between the two replay variants; the lean grid's stream waits for it
   uint32_t n_heavy, n_lean, mode;
   const uint32_t* d_index;
   uint32_t off, period;

@@ -1415,7 +1415,7 @@ constexpr int kLean = 0, kReplayShort = 1, kReplayLong = 2;
 // actions in the best list up to which replay episodes stay on the exact scan (measured at 16 384 x 10 %: a batch with an
 // 82-action list — 90 generators per replay episode — takes 2.02 ms this side of the limit and 2.37 ms on the other, one
 // with a 109-action list — 117 generators — 2.39 against 2.25)
-constexpr int kShortReplayMax = 96;
+// (kShortReplayMax = 96, eg_internal.h)
 template <int kHelpers, int kKind>
 __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? 2 : 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
@@ -2324,6 +2324,10 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     //  256-register wave of the long one, when IT has nothing to do, must wait until a SIMD full of lean waves has drained two
     //  of them, and whatever is queued behind it on the stream waits with it — measured: 0.6 ms)
     launch_variant<kReplayShort>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, p.ev[0], nullptr);
+    if (p.go_event && p.n_lean > 0) {
+      (void)hipEventRecord((hipEvent_t)p.go_event, (hipStream_t)p.stream_heavy);
+      (void)hipStreamWaitEvent((hipStream_t)p.stream_lean, (hipEvent_t)p.go_event, 0);
+    }
     launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, p.ev[1]);
   }
   if (p.n_lean > 0) {
