@@ -167,6 +167,34 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert 0.0 < line["roofline"]["frac"] <= 1.0 and line["roofline"]["touched_bytes_per_launch"] > 0
 
 
+def test_bench_line_contract_on_one_gpu():
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's keys (steps / warmup echoed), the `roofline`
+    and `cpu_baseline` objects, and the two secondary objects; no episode fails; every batch started from the same policy."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--episodes", "2048",
+                          "--min-seconds", "0.05"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    for key, want in (("metric", "26-year episodes/sec"), ("unit", "episodes/s"), ("n_gpus", 1), ("steps", 3), ("warmup", 1),
+                      ("higher_is_better", True), ("scaling", "weak"), ("vs_baseline", None), ("dtype", "f64"), ("data", "synthetic")):
+        assert line[key] == want, key
+    assert line["value"] > 0 and abs(line["ms_per_step"] - line["ms_per_batch"] * line["batches_per_step"]) < 1e-6 * line["ms_per_step"]
+    cfg = line["config"]
+    assert "workload" in cfg and cfg["episodes_failed"] == 0 and cfg["last_batch"]["ok"] == 2048 and cfg["policy"].startswith("pinned")
+    assert cfg["replay"]["best_list_len"] == 28 and cfg["last_batch"]["generators_per_replay_episode"] == 35.0      # config 1's episode, replayed
+    r = line["roofline"]
+    assert r["bound"] and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert "traffic" in r and r["avg_kernel_ms"] > 0
+    g = line["config2_grown"]
+    assert g["value"] > 0 and g["episodes_failed"] == 0 and g["replay"]["best_list_len"] > 96 and g["last_batch"]["generators_per_replay_episode"] > 100
+    assert line["config1"]["value"] > 0 and line["config1"]["episodes_failed"] == 0
+    c = line["cpu_baseline"]
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "episodes/s" and c["sample"]
+
+
 def test_train_step_equals_the_stepwise_path(engine):
     """eg_train_step (one library call per step) == upload + launch_update + packet copy + apply, bit for bit."""
     from eirgrid_amd.engine import apply_packet
