@@ -351,7 +351,16 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
     for (int k = 0; k < 4; ++k)
       if (hipEventCreate(&c->ev[i][k]) != hipSuccess) { set_error("hipEventCreate failed"); rc = EG_ERR_HIP; break; }
-  if (rc == EG_OK && hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); rc = EG_ERR_HIP; }
+  if (rc == EG_OK) {
+    // A priority of its own gives the stream a hardware queue of its own.  (A plain stream created after torch / RCCL have made
+    // theirs ended up sharing one with the null stream: the grids of a batch then ran one after the other — measured.)
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const char* sp = std::getenv("EIRGRID_SIDE_STREAM");      // diagnostics: "plain" = no priority
+    const bool plain = sp && std::string(sp) == "plain";
+    if ((plain ? hipStreamCreateWithFlags(&c->stream_heavy, hipStreamNonBlocking)
+               : hipStreamCreateWithPriority(&c->stream_heavy, hipStreamNonBlocking, greatest)) != hipSuccess) { set_error("hipStreamCreate failed"); rc = EG_ERR_HIP; }
+  }
   for (int i = 0; i < eg_ctx::kTimingRing && rc == EG_OK; ++i)
     if (hipEventCreateWithFlags(&c->ev_fork[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_go[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess) {
