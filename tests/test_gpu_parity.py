@@ -468,6 +468,45 @@ def test_heavy_episodes_match_the_oracle(world):
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
 
 
+def test_field_pool_grows_with_the_launch(world):
+    """More replay episodes in one launch than the field pool starts with (4 096 slots): the pool is enlarged before the launch,
+    so none of them falls back to the exact scan (20-40x slower, and a launch lasts as long as its slowest episode), and
+    episodes beyond the old pool size are still the oracle's, bit for bit."""
+    tb = _tabled(world)
+    rng = np.random.default_rng(23)
+    pol = ActionWeights()
+    run = [[int(3 * rng.choice([0, 4, 12, 7]) + rng.integers(0, 3)) for _ in range(7)] for _ in range(26)]
+    nr = np.array([len(l) for l in run], np.int32); nd = np.zeros(26, np.int32)
+    pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.array([a for l in run for a in l], np.uint8), nd, np.zeros(0, np.uint8))
+    n = 4608
+    mask = np.ones(n, np.uint8)
+    out, ms = {}, {}
+    for slots in (None, "4096"):      # the default (grows with the launch) and a pool held at its initial size
+        if slots is not None:
+            os.environ["EIRGRID_HEAVY_SLOTS"] = slots
+        try:
+            eng = Engine(world, device=0)
+        finally:
+            os.environ.pop("EIRGRID_HEAVY_SLOTS", None)
+        try:
+            eng.rollout_batch(pol, 99, 64, replay_mask=mask[:64])      # (the pool exists at its initial size now)
+            eng.timing_reset()
+            out[slots] = eng.rollout_batch(pol, 99, n, replay_mask=mask)
+            t, launches = eng.timing_read()
+            ms[slots] = t / max(launches, 1)
+        finally:
+            eng.close()
+    res = out[None]
+    assert (res.status == 0).all() and int(res.n_gens.min()) >= 150
+    for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_gens", "bytes_moved"):
+        assert getattr(res, name).tobytes() == getattr(out["4096"], name).tobytes(), name
+    for e in (0, 4095, 4096, 4300, n - 1):
+        st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 99 + e, replay=True)
+        assert_episode_equal(res, e, ref, f"episode {e} of {n} replays")
+    print(f"{n} replay episodes of {res.n_gens.mean():.0f} generators: {ms[None]:.2f} ms; with 512 of them on the exact scan: {ms['4096']:.2f} ms")
+    assert ms[None] < 0.75 * ms["4096"]
+
+
 def test_find_suitable_location_with_the_reference_signature(engine, oracle_world):
     """B2 as the reference declares it (metal_location_search.rs:96-103): generators at arbitrary coordinates (off the 1 km
     grid, on it, on top of candidates, outside every radius) and an f32 size penalty — cell AND score bit-identical to the
