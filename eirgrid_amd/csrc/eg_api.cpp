@@ -119,7 +119,7 @@ int ensure_outputs(eg_ctx* c, uint32_t n) {
   return EG_OK;
 }
 
-// collects the oldest `count` recorded launches (all of them when count < 0).  A batch that ran as two grids counts as
+// collects the oldest `count` recorded launches (all of them when count < 0).  A batch that ran as several grids counts as
 // ONE launch lasting from the earlier start to the later end.
 int collect_timing(eg_ctx* c, int count = -1) {
   if (count < 0 || count > c->ring_pending) count = c->ring_pending;
@@ -174,8 +174,8 @@ int prepare_heavy(eg_ctx* c, uint32_t n_heavy) {
   c->dev.heavy_epoch = c->launch_epoch;
   return EG_OK;
 }
-// One batch = up to two grids of k_rollout (eg_internal.h RolloutPlan): the episodes that replay the best strategy on the
-// heavy-capable variant, the others on the lean one, on two streams side by side.  `host_mask` (n bytes, may be NULL):
+// One batch = up to three grids of k_rollout (eg_internal.h RolloutPlan): the episodes that replay the best strategy on the
+// two replay variants (one of which returns at once), the others on the lean one, on two streams side by side.  `host_mask` (n bytes, may be NULL):
 // which episodes replay; otherwise `period` (0: none): episode i replays when (first_index + i) % period == 0.
 // Uploads the mask and the index lists, takes a slot of the timing ring, gives the launch its field-pool epoch, launches.
 int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, const uint8_t* host_mask, uint32_t period, long long* d_stats) {

@@ -238,9 +238,10 @@ double action_cost_estimate(int action, int year_index);      // eg_tables.cpp; 
 // launchers implemented in eg_rollout.hip
 struct StatsParams;
 struct UpdateCandidate;
-// How a batch is split over the two variants of k_rollout (eg_rollout.hip, EpisodeMap): n_heavy episodes — the ones that
-// replay the best strategy — on the heavy-capable variant, n_lean on the lean one, on two streams side by side when both
-// are present.  mode 1: d_index holds the n_heavy replay episodes followed by the n_lean others; mode 2: the replays are
+// How a batch is split over the variants of k_rollout (eg_rollout.hip, EpisodeMap): n_heavy episodes — the ones that replay
+// the best strategy — on the two replay variants (the short-replay and the heavy-capable one: the one whose turn it is not
+// returns at once), n_lean on the lean one; on two streams side by side when both are present (stream_heavy: the library's
+// side stream, stream_lean: the null stream).  mode 1: d_index holds the n_heavy replay episodes followed by the n_lean others; mode 2: the replays are
 // off + period * j.  ev: start / stop events of the heavy and of the lean grid (only the ones launched are recorded).
 struct RolloutPlan {
   bool helper_waves;

@@ -1385,9 +1385,10 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
 #define EG_TE(slot) do {} while (0)
 #endif
 
-// Which episode of the batch a workgroup runs.  A batch is launched as up to two grids that run side by side on two
+// Which episode of the batch a workgroup runs.  A batch is launched as up to three grids that run side by side on two
 // streams: the episodes that replay the best strategy — the ones that grow long generator lists, SURVEY Q15 — on the
-// kHeavy variant of the kernel (approximate-field placement from kHeavyGens generators on), all others on the lean
+// replay variants of the kernel (kReplayLong: approximate-field placement from kHeavyGens generators on; kReplayShort: the
+// exact scan, for short lists; see k_rollout), all others on the lean
 // variant, whose code and registers are those of a kernel without the heavy path (measured: with the heavy calls compiled
 // into the one kernel, sampled episodes ran 8 % / 13 % slower at 1 024 / 16 384 episodes).
 struct EpisodeMap {
