@@ -320,6 +320,23 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         }
       }
   }
+  {  // compact factor table (eg_rollout.hip load_factor_table): class k keeps squared distances 0..cap_k, cap_k = the first at which
+     // the factor is 1.0 (d >= R); the factor must depend on the squared distance only and reach 1.0 within 12 cells
+    int32_t* meta = reinterpret_cast<int32_t*>(blob.data() + tab::dr_meta);
+    int next = 0;
+    for (int k = 0; k < kRadiusClasses && rc == EG_OK; ++k) {
+      int cap = 1 << 30;
+      for (int ai = 0; ai <= kMaxReach; ++ai) for (int aj = 0; aj <= kMaxReach; ++aj)
+        if (H.dr[(size_t(k) * 13 + ai) * 13 + aj] == 1.0 && ai * ai + aj * aj < cap) cap = ai * ai + aj * aj;
+      bool radial = cap <= kMaxReach * kMaxReach;
+      for (int ai = 0; ai <= kMaxReach && radial; ++ai) for (int aj = 0; aj <= kMaxReach; ++aj)
+        if ((H.dr[(size_t(k) * 13 + ai) * 13 + aj] == 1.0) != (ai * ai + aj * aj >= cap)) { radial = false; break; }
+      if (!radial || cap > 255) { set_error("eg_create: the distance factors of a radius class are not a function of the squared distance that reaches 1.0 within 12 cells"); rc = EG_ERR_BAD_ARG; break; }
+      meta[k] = next; meta[8 + k] = cap;
+      next += (cap + 1 + 1) & ~1;      // entries 0..cap, every class starts at an even entry
+    }
+    if (rc == EG_OK && next > kDrCompact) { set_error("eg_create: radii too large for the compact factor table"); rc = EG_ERR_BAD_ARG; }
+  }
   {  // heavy episodes (eg_rollout.hip heavy_add): every (class, di, dj) with a factor below 1, i.e. closer than the class radius
     uint32_t* box = reinterpret_cast<uint32_t*>(blob.data() + tab::hv_box);
     int nbox = 0;
@@ -328,13 +345,13 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         for (int dj = -kMaxReach; dj <= kMaxReach; ++dj) {
           const int ai = di < 0 ? -di : di, aj = dj < 0 ? -dj : dj;
           if (H.dr[(size_t(k) * 13 + ai) * 13 + aj] == 1.0) continue;
-          if (nbox < 1024) box[nbox] = uint32_t(di + 16) | (uint32_t(dj + 16) << 5) | (uint32_t(di * di + dj * dj) << 10) | (uint32_t(k) << 18);
+          if (nbox < 1024) box[nbox] = uint32_t(di + 16) | (uint32_t(dj + 16) << 5) | (uint32_t(di * di + dj * dj) << 10) | (uint32_t(k) << 19);
           ++nbox;
         }
     if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
     for (int i = nbox; i < 1024; ++i) box[i] = 145u << 10;      // padding: class 0, di = dj = -16 (no class reaches that far), q = 145 (factor 1.0)
     for (int k = 0, i = 0; k <= kRadiusClasses; ++k) {      // words 1024..1030: where class k starts (the list is sorted by class), then the end
-      while (i < nbox && i < 1024 && int(box[i] >> 18) < k) ++i;
+      while (i < nbox && i < 1024 && int(box[i] >> 19) < k) ++i;
       box[1024 + k] = uint32_t(i);
     }
   }

@@ -18,6 +18,7 @@ constexpr int kMaxReach = 12;   // cells; the largest penalty radius is 12 km
 constexpr int kMults = 3;
 constexpr int kOffsetTypes = 4;
 constexpr int kPsStride = 2624;   // sorted candidate lists on the device: 41 chunks of 64 (2601 -> 2624 entries)
+constexpr int kDrCompact = 352;      // doubles of the compact factor table (the reference's six radii need 333)
 constexpr int kShortReplayMax = 96;   // actions in the best list up to which replay episodes stay on the exact scan (eg_rollout.hip, k_rollout kinds)
 constexpr int kMaxVariants = 12;  // distinct (radius class, marine) pairs over the 15 types (8 for the reference's types)
 
@@ -96,7 +97,10 @@ constexpr size_t offc = a16(offv + 8 * kYears * kOffsetTypes * kYears);     // [
 constexpr size_t cc = a16(offc + 8 * kYears * kOffsetTypes * kMults);       // [26][15][26][3][2]
 constexpr size_t ps = a16(cc + 8 * size_t(kYears) * kTypes * kYears * kMults * 2);   // PsRec [26][kMaxVariants][kPsStride]
 constexpr size_t hv_box = a16(ps + sizeof(PsRec) * size_t(kYears) * kMaxVariants * kPsStride);   // u32 [1024 + 16]: heavy episodes, eg_rollout.hip heavy_add
-constexpr size_t total = hv_box + 4 * (1024 + 16);
+// the throughput kernels' factor table in LDS holds every radius class only up to its own radius (eg_rollout.hip load_factor_table):
+// int32 {first entry of class k} [8] | {squared distance from which the factor is 1.0, class k} [8]
+constexpr size_t dr_meta = a16(hv_box + 4 * (1024 + 16));
+constexpr size_t total = dr_meta + 4 * 16;
 }  // namespace tab
 
 struct DevTables {
@@ -116,7 +120,7 @@ struct DevTables {
   EG_TAB(reach, int32_t)
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  EG_TAB(ps, PsRec)
+  EG_TAB(ps, PsRec) EG_TAB(dr_meta, int32_t)
 #undef EG_TAB
 };
 

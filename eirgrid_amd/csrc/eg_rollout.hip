@@ -67,7 +67,9 @@ __device__ __forceinline__ int deficit_slot_of(int action) {
 }
 
 struct __align__(16) Smem {
-  double dr[kRadiusClasses * kD2Stride];   // d/R by squared cell distance min(di^2 + dj^2, 144) for every radius class; 1.0 where d >= R
+  double dr[kDrCompact];              // d/R by squared cell distance, class k at entries off_k .. off_k + cap_k (tab::dr_meta): only up to its own
+                                      // radius — 1.0 at cap_k, where every larger distance is capped (2.7 instead of 7 KB: with 128 VGPRs that is
+                                      // what lets a fourth wave share the SIMD)
   int gstage[2][kWave + 8];           // per wave: (gi, gj) as two int16 of the 64 generators being folded (read back four at a time);
                                       // the tail stays at the off-grid padding value: the pipeline reads up to three groups ahead
   double scaled[64];                  // stalled sampler: weights^p in sorted order
@@ -258,11 +260,16 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 __device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) {
   // tails of the staging rows of chunk_product: generators far off the grid (their factor is 1.0), never overwritten
   if (lane < 8) { sm.gstage[0][kWave + lane] = (int)0xC000C000; sm.gstage[1][kWave + lane] = (int)0xC000C000; }
-  for (int i = lane; i < kRadiusClasses * kD2Stride; i += kWave) sm.dr[i] = 1.0;
+  for (int i = lane; i < kDrCompact; i += kWave) sm.dr[i] = 1.0;
   for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
     const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
-    if (q <= kD2Max) sm.dr[rc * kD2Stride + q] = T.dr()[i];
+    if (q < T.dr_meta()[8 + rc]) sm.dr[T.dr_meta()[rc] + q] = T.dr()[i];
   }
+}
+// byte offset of a radius class's factors inside the LDS block | its cap << 16: what chunk_product / factor_by_q take as `table`
+// in the throughput kernels (from the type's info word: bits 16-23 cap, 24-31 first entry / 2)
+__device__ __forceinline__ int throughput_table(int info) {
+  return ((int)offsetof(Smem, dr) + (int)(((unsigned)info >> 24) << 4)) | (((info >> 16) & 255) << 16);
 }
 // small-batch kernel: the generator list starts as padding everywhere; the factor table goes in at a stride of 16 bytes
 __device__ __forceinline__ void load_latency_tables(const DevTables& T, int lane) {
@@ -277,7 +284,8 @@ __device__ __forceinline__ void load_static_tables(const DevTables& T, int lane,
   if (with_factors) load_factor_table(T, lane);
   if (lane < kTypes) {
     const int rc = T.rclass()[lane];
-    sm.type_info[lane] = T.variant()[lane] | (rc << 4) | (T.reach()[rc] << 8) | (T.cls()[lane] << 12);
+    sm.type_info[lane] = T.variant()[lane] | (rc << 4) | (T.reach()[rc] << 8) | (T.cls()[lane] << 12) | (T.dr_meta()[8 + rc] << 16) |
+                         (int)((unsigned)(T.dr_meta()[rc] >> 1) << 24);
     sm.type_out[lane] = T.out_mw()[lane];
     sm.type_co2[lane] = T.co2_t()[lane];
   }
@@ -369,11 +377,11 @@ __device__ __noinline__ int weighted_pick(int table_offset, int n, double u, int
 typedef short short2v __attribute__((ext_vector_type(2)));
 // factor of one generator for this lane's candidate: (ci - gi, cj - gj) as two int16, their squared length by one dot
 // product, capped at 144 (12 km, the largest radius: the table holds 1.0 there)
-__device__ __forceinline__ double factor_at(short2v cpk, int gen_packed, int table_offset) {
+__device__ __forceinline__ double factor_at(short2v cpk, int gen_packed, int table_offset, int cap) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
   const short2v d = cpk - g;
   int q = __builtin_amdgcn_sdot2(d, d, 0, false);
-  q = q < kD2Max ? q : kD2Max;
+  q = q < cap ? q : cap;      // (the class's own radius squared: the table holds 1.0 there)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + (table_offset + q * 8));
 }
 
@@ -393,11 +401,11 @@ struct PrefixCache { double product; int key; int count; };      // key: year <<
 // The packed coordinates of 64 generators are staged in LDS once and come back four at a time as ONE broadcast 128-bit
 // read (instead of a readlane and a lane-index add each); per generator that leaves a packed subtract, the dot product,
 // the cap, the address, the table read and the multiply.
-__device__ __forceinline__ double chunk_product(const double* dr, int lane, int k0, int ngen_s, double s_init, int cell, int stage) {
+__device__ __forceinline__ double chunk_product(int table, int lane, int k0, int ngen_s, double s_init, int cell, int stage) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
-  const int dr_off = (int)(reinterpret_cast<const char*>(dr) - reinterpret_cast<const char*>(&sm));   // table base inside the LDS block
+  const int dr_off = table & 0xFFFF, cap = table >> 16;   // throughput_table(): the class's factors inside the LDS block, and where they end
   int* row = sm.gstage[stage];
   const int4* row4 = reinterpret_cast<const int4*>(row);
   const int k0_s = __builtin_amdgcn_readfirstlane(k0);           // uniform (it comes out of a per-wave cache): scalar loop control
@@ -414,8 +422,8 @@ __device__ __forceinline__ double chunk_product(const double* dr, int lane, int 
     // out-of-range generators and the padding up to a multiple of four multiply by 1.0 instead of branching.
     // Software-pipelined: while four factors are multiplied in list order (only the multiplies form a chain) the next
     // four are on their way from the table; two register sets take turns.
-#define EG_FACTORS_LOOSE(g4, f0, f1, f2, f3) { f0 = factor_at(cpk, g4.x, dr_off); f1 = factor_at(cpk, g4.y, dr_off); \
-                                               f2 = factor_at(cpk, g4.z, dr_off); f3 = factor_at(cpk, g4.w, dr_off); }
+#define EG_FACTORS_LOOSE(g4, f0, f1, f2, f3) { f0 = factor_at(cpk, g4.x, dr_off, cap); f1 = factor_at(cpk, g4.y, dr_off, cap); \
+                                               f2 = factor_at(cpk, g4.z, dr_off, cap); f3 = factor_at(cpk, g4.w, dr_off, cap); }
     double a0, a1, a2, a3, b0, b1, b2, b3;
     int4 gc = row4[0], gn = row4[1];
     EG_FACTORS_LOOSE(gc, a0, a1, a2, a3)
@@ -525,13 +533,13 @@ __device__ __forceinline__ double chunk_product_latency(int class_off, int k0, i
 }
 // Final score of this lane's candidate (rank r of the sorted list) against the episode's generator list.
 // kLatency: small-batch kernel (`table` = byte offset of the radius class inside sl.dr16, xy4 = the candidate's packed
-// coordinates); otherwise the throughput kernel (`table` = byte offset of the class inside sm.dr, `cell`).
+// coordinates); otherwise the throughput kernel (`table` = throughput_table() of the type, `cell`).
 template <bool kLatency>
 __device__ __forceinline__ double chunk_score(int table, double size_factor, int lane, int ngen_s, int r, double te,
                                               double cf, int cell, int xy4) {
   double p;
   if constexpr (kLatency) p = chunk_product_latency<false>(table, 0, ngen_s, te, xy4);
-  else p = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, 0, ngen_s, te, cell, 0);
+  else p = chunk_product(table, lane, 0, ngen_s, te, cell, 0);
   const double s = (p * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
@@ -542,7 +550,7 @@ __device__ __forceinline__ double chunk_score(int table, double size_factor, int
   double s = te; int k0 = 0;
   if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
   if constexpr (kLatency) s = stage ? chunk_product_latency<true>(table, k0, ngen_s, s, xy4) : chunk_product_latency<false>(table, k0, ngen_s, s, xy4);
-  else s = chunk_product(reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table), lane, k0, ngen_s, s, cell, stage);
+  else s = chunk_product(table, lane, k0, ngen_s, s, cell, stage);
   cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
   return r < kCells ? s : 0.0;
@@ -794,7 +802,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   const int v = info & 15, rc = (info >> 4) & 15;
   const PsRec* __restrict__ list = T.ps() + (size_t)(yi * kMaxVariants + v) * kPsStride;
   // factor table of the radius class: byte offset inside sl.dr16 (small-batch kernel) / inside the LDS block (sm.dr)
-  const int table = kHelpers > 0 ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
+  const int table = kHelpers > 0 ? rc * (kD2Stride * 16) : throughput_table(info);
   const double size_factor = T.size_factor;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
@@ -931,11 +939,15 @@ __device__ __forceinline__ PsRec load_rec(unsigned long long list_addr, int i) {
 __device__ __forceinline__ double field_load(GlobalF64 p) {      // past the CU's L1: the wave wrote this entry itself
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// q: squared cell distance, already capped (kLatency: at kD2Max; otherwise at the class's own cap, table >> 16).  `table`: the
+// class's throughput_table() — the small-batch kernel (kLatency) has the full table at a 16-byte stride and goes by `rc`.
 template <bool kLatency>
-__device__ __forceinline__ double factor_by_q(int rc, int q) {
+__device__ __forceinline__ double factor_by_q(int rc, int table, int q) {
   if constexpr (kLatency) return sl.dr16[2 * (rc * kD2Stride + q)];
-  else return sm.dr[rc * kD2Stride + q];
+  else return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + ((table & 0xFFFF) + q * 8));
 }
+template <bool kLatency>
+__device__ __forceinline__ int factor_cap(int table) { return kLatency ? kD2Max : table >> 16; }
 // one slot of the pool for this launch, or -2 (pool exhausted / absent).  The claim word holds launch epoch << 20 | count,
 // so no launch has to reset it: the first claim of a launch swaps the new epoch in with a zero count, every claim is then
 // ONE fetch-and-add (a compare-and-swap loop here made 1 638 episodes queue behind each other for milliseconds).
@@ -967,23 +979,33 @@ __device__ __forceinline__ int heavy_claim(const DevTables& T, int lane) {
 constexpr int kBoxEntries = 1024;
 constexpr uint32_t kBoxPadding = 145u << 10;      // class 0, di = dj = -16, q = 145: a factor of exactly 1.0 (sm.dr is padded with it)
 struct __align__(16) SmemHeavy {
-  uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 | class << 18
+  uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 (9 bits; throughput kernels: place in sm.dr) | class << 19
 };
 __shared__ SmemHeavy sh;
 typedef const uint32_t __attribute__((address_space(1)))* GlobalU32c;
 // sh.box = the entries of the radius classes in `classes` (the host's list is sorted by class; its words 1024..1030 are where
 // each class starts), padded to a multiple of four per lane; returns that multiple (1..4)
-__device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, int lane, int classes) {
+// Throughput kernels (!kLatency): the squared distance of an entry is replaced by the entry's place in the compact factor table
+// sm.dr (`meta_addr`: tab::dr_meta), so that heavy_add reads the factor without knowing the class's offset and cap.
+template <bool kLatency>
+__device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, unsigned long long meta_addr, int lane, int classes) {
   const GlobalU32c src = (GlobalU32c)box_addr;
+  const GlobalU32c meta = (GlobalU32c)meta_addr;
+  auto place = [&](uint32_t en) -> uint32_t {
+    if constexpr (kLatency) return en;
+    const int rc = (int)(en >> 19), q = (int)((en >> 10) & 511u);
+    const int off = (int)meta[rc], cap = (int)meta[8 + rc];
+    return (en & ~(511u << 10)) | ((uint32_t)(off + (q < cap ? q : cap)) << 10);
+  };
   int n = 0;
   for (int rc = 0; rc < kRadiusClasses; ++rc) {
     if (!((classes >> rc) & 1)) continue;
     const int s0 = __builtin_amdgcn_readfirstlane((int)src[kBoxEntries + rc]), s1 = __builtin_amdgcn_readfirstlane((int)src[kBoxEntries + rc + 1]);
-    for (int i = s0 + lane; i < s1; i += kWave) sh.box[n + i - s0] = src[i];
+    for (int i = s0 + lane; i < s1; i += kWave) sh.box[n + i - s0] = place(src[i]);
     n += s1 - s0;
   }
   const int padded = (n + 4 * kWave - 1) & ~(4 * kWave - 1);
-  for (int i = n + lane; i < padded; i += kWave) sh.box[i] = kBoxPadding;
+  for (int i = n + lane; i < padded; i += kWave) sh.box[i] = place(kBoxPadding);
   wave_sync();
   return padded / (4 * kWave);
 }
@@ -1001,9 +1023,9 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k) {
     const uint32_t en = ens[k];
-    const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 18);
+    const int ci = gi + (int)(en & 31u) - 16, cj = gj + (int)((en >> 5) & 31u) - 16, rc = (int)(en >> 19);
     const bool inside = (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid;
-    fac[k] = factor_by_q<kLatency>(rc, (int)((en >> 10) & 255u));
+    fac[k] = factor_by_q<kLatency>(rc, (int)offsetof(Smem, dr), (int)((en >> 10) & 511u));      // (throughput kernels: the entry's place in sm.dr, see heavy_pack_list)
     off[k] = rc * kFieldStride + (inside ? ci * kGrid + cj : kCells);
     val[k] = field_load(base + off[k]);
   }
@@ -1018,10 +1040,11 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 // field only serves a bound).  The field of the 41 blocks of 64 cells sits in registers while the generators pass by; a
 // generator only touches the blocks whose rows come within `reach` of its own row (a scalar test per block).
 template <bool kLatency>
-__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int reach, int ngen) {
+__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int table, int reach, int ngen) {
   const GlobalF64 f = (GlobalF64)class_addr;
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double p[kChunks];
+  const int cap = factor_cap<kLatency>(table);
 #pragma unroll
   for (int ch = 0; ch < kChunks; ++ch) p[ch] = 1.0;
   for (int g = 0; g < ngen; ++g) {
@@ -1034,8 +1057,8 @@ __device__ __noinline__ void heavy_build_class(unsigned long long class_addr, in
       const int cell = ch * kWave + lane;
       const int ci = cell / kGrid, cj = cell - ci * kGrid;
       int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
-      q = q < kD2Max ? q : kD2Max;
-      p[ch] = p[ch] * factor_by_q<kLatency>(rc, q);
+      q = q < cap ? q : cap;
+      p[ch] = p[ch] * factor_by_q<kLatency>(rc, table, q);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
@@ -1049,8 +1072,9 @@ __device__ __noinline__ void heavy_build_class(unsigned long long class_addr, in
 // fed by v_readlane.  The winner of a search is a cell that few generators reach: a handful of multiplications instead
 // of one per generator (chunk_product, which evaluates 64 different candidates at once, cannot skip anything).
 template <bool kLatency>
-__device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double te, int cell, int lane) {
+__device__ __forceinline__ double exact_product_chain(int rc, int table, int ngen_s, double te, int cell, int lane) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
+  const int cap = factor_cap<kLatency>(table);
   double s = te;
   for (int gb = 0; gb < ngen_s; gb += kWave) {
     double f = 1.0;
@@ -1058,8 +1082,8 @@ __device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double
       const int gc = (int)(sm.gcell[gb + lane] & 0xFFF);
       const int gi = gc / kGrid, gj = gc - gi * kGrid;
       int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
-      q = q < kD2Max ? q : kD2Max;
-      f = factor_by_q<kLatency>(rc, q);
+      q = q < cap ? q : cap;
+      f = factor_by_q<kLatency>(rc, table, q);
     }
     unsigned long long near = __ballot(f != 1.0);
     while (near != 0ull) {
@@ -1073,7 +1097,7 @@ __device__ __forceinline__ double exact_product_chain(int rc, int ngen_s, double
 // `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
 // returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
 template <bool kLatency>
-__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, double size_factor, int lane, int rc, int ngen) {
+__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, double size_factor, int lane, int rc, int tbl, int ngen) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1162,20 +1186,20 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   if (ncand == 1 && solo >= 0) {      // the usual case: one candidate, its record still in the lane that found it
     const double te1 = readlane_f64(q1te, solo), cf1 = readlane_f64(q1cf, solo);
     const int cell1 = __builtin_amdgcn_readlane(q1cell, solo);
-    b.score = (exact_product_chain<kLatency>(rc, ngen_s, te1, cell1, lane) * cf1) * size_factor;
+    b.score = (exact_product_chain<kLatency>(rc, tbl, ngen_s, te1, cell1, lane) * cf1) * size_factor;
     b.cell = cell1; b.m03 = readlane_f64(q1m03, solo);
   } else if (ncand <= 4) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
     for (int k = 0; k < ncand; ++k) {
       const int rk = __builtin_amdgcn_readfirstlane(sm.gstage[1][k]);
       const PsRec e = load_rec(list_addr, rk);      // the same record in every lane
-      const double sk = (exact_product_chain<kLatency>(rc, ngen_s, e.te, (int)e.cell, lane) * e.cf) * size_factor;
+      const double sk = (exact_product_chain<kLatency>(rc, tbl, ngen_s, e.te, (int)e.cell, lane) * e.cf) * size_factor;
       if (sk > b.score || (sk == b.score && sk > 0.0 && (int)e.cell < b.cell)) { b.score = sk; b.cell = (int)e.cell; b.m03 = e.m03; }
     }
   } else {               // many ties: 64 candidates at once (chunk_product)
     const int r = lane < ncand ? sm.gstage[1][lane] : kCells;
     PsRec e; e.te = 0.0; e.cf = 1.0; e.m03 = 0.0; e.cell = 0u; e.pad = 0u;
     if (r < kCells) e = load_rec(list_addr, r);
-    const int table = kLatency ? rc * (kD2Stride * 16) : (int)offsetof(Smem, dr) + rc * (kD2Stride * 8);
+    const int table = kLatency ? rc * (kD2Stride * 16) : tbl;
     const double s = chunk_score<kLatency>(table, size_factor, lane, ngen_s, r, e.te, e.cf, (int)e.cell, (int)e.pad);
     b = chunk_reduce<false>(s, (int)e.cell, e.m03);
   }
@@ -1418,7 +1442,7 @@ constexpr int kLean = 0, kReplayShort = 1, kReplayLong = 2;
 // with a 109-action list — 117 generators — 2.39 against 2.25)
 // (kShortReplayMax = 96, eg_internal.h)
 template <int kHelpers, int kKind>
-__global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? 2 : 3) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? 2 : (kHelpers > 0 ? 3 : 4)) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
                                                                     const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
                                                                     long long* stats, EpisodeMap emap) {
@@ -1686,15 +1710,15 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             const int hv = info & 15, hrc = (info >> 4) & 15;
             const unsigned long long class_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull;
             if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
-              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, (info >> 8) & 15, ep.ngen);
+              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, throughput_table(info), (info >> 8) & 15, ep.ngen);
               ep.heavy_classes |= 1 << hrc;
-              ep.heavy_quads = heavy_pack_list((unsigned long long)(T.base + tab::hv_box), lane, ep.heavy_classes);
+              ep.heavy_quads = heavy_pack_list<(kHelpers > 0)>((unsigned long long)(T.base + tab::hv_box), (unsigned long long)(T.base + tab::dr_meta), lane, ep.heavy_classes);
             }
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
 #endif
             const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride), class_addr,
-                                                        T.size_factor, lane, hrc, ep.ngen);
+                                                        T.size_factor, lane, hrc, throughput_table(info), ep.ngen);
 #ifdef EG_STAMPS
             const unsigned long long th1 = __builtin_readcyclecounter();
             stamps[9] += th1 - th0;
