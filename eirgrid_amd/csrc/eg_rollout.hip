@@ -13,7 +13,8 @@
 // Two measured facts shape the code: (1) in the small-batch kernel a lone wave issues one instruction per turn of its
 // SIMD, whatever the instruction — the hot loops are written for instruction count, scalar and wait instructions
 // included (chunk_product_latency); (2) gfx950 allocates LDS in 1280-byte granules — the throughput kernel's Smem is
-// held at ten of them (twelve episodes per CU), the small-batch kernel spends LDS freely (SmemLatency).
+// held at seven of them (room for eighteen episodes per CU; sixteen run: four waves per SIMD at 128 VGPRs), the small-batch kernel
+// spends LDS freely (SmemLatency).
 //
 // Reference (paths relative to /root/reference/aiSimulator/src/):
 //   episode        core/simulation.rs:22-317, core/iteration.rs:57-74
@@ -98,10 +99,11 @@ struct __align__(16) Smem {
   unsigned long long hdbg[2][4];
 #endif
 };
-// gfx950 hands out LDS in granules of 1280 bytes (160 KB / 128): ten granules per episode is what lets twelve workgroups
-// share a CU, the same limit as three waves per SIMD.  One byte more costs a twelfth of the throughput kernel.
+// gfx950 hands out LDS in granules of 1280 bytes (160 KB / 128): seven granules per episode leave room for the sixteen workgroups per
+// CU that four waves per SIMD (128 VGPRs) allow.  (Ten granules and three waves until the factor table was compacted: 1.305 -> 1.194 ms
+// at 16 384 episodes.)
 #ifndef EG_STAMPS
-static_assert(sizeof(Smem) <= 10 * 1280, "twelve episodes per CU");
+static_assert(sizeof(Smem) <= 7 * 1280, "sixteen episodes per CU");
 #endif
 
 // One instance per workgroup (= per episode).  File scope so that non-inlined helpers address it as LDS.
@@ -397,7 +399,7 @@ struct PrefixCache { double product; int key; int count; };      // key: year <<
 // fewest instructions per generator: the packed coordinates of 64 generators are staged in LDS once and come back four
 // at a time as ONE broadcast 128-bit read (instead of a readlane and a lane-index add each); per generator that leaves a
 // packed subtract, the dot product, the cap, the address, the table read and the multiply.
-// Throughput kernel (one wave per episode, twelve episodes per CU).  `stage`: the wave's staging row in LDS.
+// Throughput kernel (one wave per episode, sixteen episodes per CU).  `stage`: the wave's staging row in LDS.
 // The packed coordinates of 64 generators are staged in LDS once and come back four at a time as ONE broadcast 128-bit
 // read (instead of a readlane and a lane-index add each); per generator that leaves a packed subtract, the dot product,
 // the cap, the address, the table read and the multiply.
