@@ -10,7 +10,7 @@ import os
 
 YEARS, N_ACTIONS, N_DEFICIT, N_COUNTS, N_TYPES = 26, 61, 15, 21, 15
 GRID, CELLS, YEARLY_FIELDS = 51, 2601, 21
-MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP = 512, 512, 2048, 1024, 1024
+MAX_GENS, MAX_OFFSETS, RUN_CAP, DEF_CAP, ACT_CAP, ONCHIP_GENS = 4096, 4096, 4096, 4096, 4096, 512
 STATS_LEN = 8 + 2 * YEARS * N_ACTIONS + YEARS * N_DEFICIT
 CANDIDATE_BYTES = 8 + 8 + 32 + 4 * YEARS + 4 * YEARS + RUN_CAP + DEF_CAP
 PACKET_BYTES = 8 * STATS_LEN + CANDIDATE_BYTES
@@ -59,7 +59,7 @@ class EgEpisodeOut(C.Structure):
 EXPORTS = [
     "eg_build_hash", "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
     "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_last_batch_size", "eg_policy_hold", "eg_policy_rewind", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_update_stats", "eg_fetch_scores",
-    "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_place", "eg_find_suitable_location", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
+    "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_best_result_track", "eg_fetch_best_result", "eg_evaluate_action_impact", "eg_place", "eg_find_suitable_location", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
     "eg_policy_push", "eg_device_rollout", "eg_device_apply", "eg_device_step", "eg_policy_pull",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
@@ -155,6 +155,12 @@ def lib():
     L.eg_export_run_details.argtypes = [C.POINTER(EgWorld), C.POINTER(C.c_char_p), C.POINTER(EgEpisodeOut), C.c_char_p, C.c_uint64]
     L.eg_fetch_record.restype = C.c_int32
     L.eg_fetch_record.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(EgEpisodeOut)]
+    L.eg_best_result_track.restype = C.c_int32
+    L.eg_best_result_track.argtypes = [C.c_void_p, C.c_int32]
+    L.eg_fetch_best_result.restype = C.c_int32
+    L.eg_fetch_best_result.argtypes = [C.c_void_p, C.POINTER(EgEpisodeOut), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    L.eg_evaluate_action_impact.restype = C.c_double
+    L.eg_evaluate_action_impact.argtypes = [_dp, _dp, C.c_int32]
     L.eg_fetch_best_run.restype = C.c_int32
     L.eg_fetch_best_run.argtypes = [C.c_void_p, C.POINTER(EgEpisodeOut), C.POINTER(C.c_int32)]
     L.eg_policy_export_improvement_csv.argtypes = [C.c_void_p, C.c_char_p]

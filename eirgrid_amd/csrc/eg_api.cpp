@@ -60,6 +60,8 @@ struct eg_ctx {
   // the whole snapshot lives in ONE device buffer filled by ONE copy from a pinned staging buffer
   uint8_t* d_snap = nullptr; uint8_t* h_snap = nullptr;
   uint8_t* d_snap_held = nullptr;      // eg_policy_hold / eg_policy_rewind
+  // the reference's best_result fold (multi_simulation.rs:613-620): 0 = not tracked, 1 = optimization_mode None, 2 = cost_only
+  int fold_mode = 0; uint8_t* d_fold = nullptr;
   // Is the best list long (the replay episodes run the heavy-capable variant and are the batch's long pole)?  As far as the host
   // knows: from the last upload or pull.  Only the ORDER of the launches depends on it (kernels decide for themselves).
   bool long_list_hint = false, long_list_hint_held = false;
@@ -231,6 +233,10 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
     EG_HIP(hipEventRecord(c->ev_join[slot], c->stream_heavy));
     EG_HIP(hipStreamWaitEvent(nullptr, c->ev_join[slot], 0));
   }
+  if (c->fold_mode != 0) {      // behind the batch on the null stream: its results are in iteration order in the records
+    const int fr = launch_fold_best(c->out, n, first_index, c->fold_mode == 2, c->d_fold, nullptr);
+    if (fr != 0) { set_error(std::string("k_fold_best launch: ") + hipGetErrorString((hipError_t)fr)); return EG_ERR_HIP; }
+  }
   c->ev_used[slot] = uint8_t((plan.n_heavy > 0 ? 1 : 0) | (plan.n_lean > 0 ? 2 : 0));
   c->ring_head = (c->ring_head + 1) % eg_ctx::kTimingRing; c->ring_pending += 1;
   c->last_n = n; c->last_first = first_index;
@@ -399,6 +405,7 @@ void eg_destroy(eg_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->d_snap) (void)hipFree(c->d_snap);
   if (c->d_snap_held) (void)hipFree(c->d_snap_held);
+  if (c->d_fold) (void)hipFree(c->d_fold);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_packet) (void)hipFree(c->d_packet);
@@ -604,6 +611,30 @@ int32_t eg_fetch_best_run(eg_ctx* c, eg_episode_out* o, int32_t* state) {
   return fetch_records(c->d_snap + snap::best_rec, 1, o);
 }
 
+int32_t eg_best_result_track(eg_ctx* c, int32_t mode) {
+  if (!c || mode < 0 || mode > 2) { set_error("eg_best_result_track: bad argument"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
+  if (mode != 0) {
+    if (!c->d_fold) EG_HIP(hipMalloc((void**)&c->d_fold, kFoldBytes));
+    EG_HIP(hipMemsetAsync(c->d_fold, 0, kFoldBytes, nullptr));      // best_result = None (multi_simulation.rs:384)
+  }
+  c->fold_mode = mode;
+  return EG_OK;
+}
+
+int32_t eg_fetch_best_result(eg_ctx* c, eg_episode_out* o, int32_t* state, int64_t* global_index) {
+  if (!c || !o || !state) { set_error("eg_fetch_best_result: bad argument"); return EG_ERR_BAD_ARG; }
+  if (!c->d_fold) { set_error("eg_fetch_best_result: eg_best_result_track first"); return EG_ERR_BAD_ARG; }
+  int rc = eg_sync(c);
+  if (rc != EG_OK) return rc;
+  FoldState st{};
+  EG_HIP(hipMemcpy(&st, c->d_fold, sizeof(st), hipMemcpyDeviceToHost));
+  *state = st.has ? 1 : 0;
+  if (global_index) *global_index = st.has ? int64_t(st.index) : -1;
+  if (!st.has) return EG_OK;
+  return fetch_records(c->d_fold + kFoldRecord, 1, o);
+}
+
 namespace { int ensure_packet(eg_ctx* c); }
 int32_t eg_train_step(eg_ctx* c, eg_policy* p, const eg_opts* o, uint64_t seed, uint64_t first_index, uint32_t n,
                       const uint8_t* replay_mask, uint64_t noise_seed) {
@@ -713,6 +744,7 @@ int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_ow
 
 int32_t eg_policy_hold(eg_ctx* c) {
   if (!c || !c->snap_valid) { set_error("eg_policy_hold: push a policy first"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
   if (!c->d_snap_held) EG_HIP(hipMalloc((void**)&c->d_snap_held, snap::total));
   EG_HIP(hipMemcpyAsync(c->d_snap_held, c->d_snap, snap::total, hipMemcpyDeviceToDevice, nullptr));
   c->long_list_hint_held = c->long_list_hint;
@@ -721,6 +753,7 @@ int32_t eg_policy_hold(eg_ctx* c) {
 
 int32_t eg_policy_rewind(eg_ctx* c) {
   if (!c || !c->d_snap_held) { set_error("eg_policy_rewind: nothing held"); return EG_ERR_BAD_ARG; }
+  EG_HIP(hipSetDevice(c->device));
   // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting; one small kernel instead of two copies)
   const int lr = launch_rewind(c->d_snap, c->d_snap_held, nullptr);
   if (lr != 0) { set_error(std::string("k_rewind launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -824,7 +857,7 @@ int32_t eg_fetch_episode_lists(eg_ctx* c, uint32_t i, double metrics[4], int32_t
 
 int32_t eg_place(eg_ctx* c, int32_t gen_type, int32_t year_index, const uint16_t* extra_cells, int32_t n_extra,
                  int32_t* out_cell, double* out_score) {
-  if (!c || gen_type < 0 || gen_type >= EG_N_TYPES || year_index < 0 || year_index >= EG_YEARS || n_extra < 0 || n_extra > EG_MAX_GENS) {
+  if (!c || gen_type < 0 || gen_type >= EG_N_TYPES || year_index < 0 || year_index >= EG_YEARS || n_extra < 0 || n_extra > EG_ONCHIP_GENS) {
     set_error("eg_place: bad argument"); return EG_ERR_BAD_ARG;
   }
   for (int i = 0; i < n_extra; ++i) if (extra_cells[i] >= EG_CELLS) { set_error("eg_place: cell out of range"); return EG_ERR_BAD_ARG; }

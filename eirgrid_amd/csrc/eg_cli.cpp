@@ -236,7 +236,9 @@ int main(int argc, char** argv) {
               (unsigned long long)a.iterations, (unsigned long long)start_iteration,
               (unsigned long long)(a.iterations > start_iteration ? a.iterations - start_iteration : 0), run_dir.c_str());
 
-  // record of the best episode (the reference's best_result, multi_simulation.rs:494-508), for the export at the end
+  // The run that is summarised and exported at the end: the reference's `best_result`, a fold over this process's iterations in
+  // iteration order that starts at None (core/multi_simulation.rs:384, :613-620; --cost-only reaches it as optimization_mode).
+  // The library folds every batch on the device behind its rollout (eg_best_result_track) and keeps the held run's record.
   struct BestRun {
     std::vector<double> metrics = std::vector<double>(4), yearly = std::vector<double>(size_t(EG_YEARS) * EG_YEARLY_FIELDS);
     std::vector<int32_t> n_act = std::vector<int32_t>(EG_YEARS); std::vector<uint8_t> act_log = std::vector<uint8_t>(EG_ACT_CAP);
@@ -256,6 +258,7 @@ int main(int argc, char** argv) {
   // reduced mode keeps the policy on the device: pushed once, every batch is enqueued without a host round trip and the
   // host copy is refreshed (eg_policy_pull) when a checkpoint or a progress line needs it
   if (reduced) CHECK(eg_policy_push(ctx, policy, &opts));
+  CHECK(eg_best_result_track(ctx, a.cost_only ? 2 : 1));
   const uint64_t full_from = a.iterations - std::min(a.iterations, final_full);   // multi_simulation.rs:437-465
   while (done < a.iterations) {
     uint32_t n = uint32_t(std::min<uint64_t>(a.batch, a.iterations - done));
@@ -279,16 +282,11 @@ int main(int argc, char** argv) {
       out.def_log = def_log.data(); out.status = status.data();
       CHECK(eg_rollout_launch(ctx, a.seed, done, n, mask.data()));
       CHECK(eg_fetch(ctx, &out));
-      int best_in_batch = -1;
       for (uint32_t i = 0; i < n; ++i)   // multi_simulation.rs:494-508, in iteration order
         if (status[i] != EG_EP_OK) failed_sequential += 1;
-        else {
-          const double before = eg_policy_get_scalar(policy, 12);      // improvements recorded so far
+        else
           CHECK(eg_policy_apply_episode(policy, &metrics[size_t(i) * 4], &n_run[size_t(i) * EG_YEARS], &run_log[size_t(i) * EG_RUN_CAP],
                                         &n_def[size_t(i) * EG_YEARS], &def_log[size_t(i) * EG_DEF_CAP], a.seed + done + i));
-          if (eg_policy_get_scalar(policy, 12) != before) best_in_batch = int(i);
-        }
-      if (best_in_batch >= 0 && a.enable_csv_export) { CHECK(eg_fetch_record(ctx, uint32_t(best_in_batch), &best_run.view)); best_run.valid = true; }
     }
     done += n;
     const auto now = std::chrono::steady_clock::now();
@@ -322,19 +320,29 @@ int main(int argc, char** argv) {
     }
   }
   CHECK(eg_policy_save_json(policy, (run_dir + "/best_weights.json").c_str()));   // multi_simulation.rs:1160-1164
+  char stamp[32]; std::string dir;
   if (a.enable_csv_export) {   // multi_simulation.rs:852-859, :912-921; csv_export.rs:114-127 (directory named after the time of export)
-    char stamp[32]; std::time_t t = std::time(nullptr); std::tm tmv; localtime_r(&t, &tmv);
+    std::time_t t = std::time(nullptr); std::tm tmv; localtime_r(&t, &tmv);
     std::strftime(stamp, sizeof(stamp), "%Y%m%d_%H%M%S", &tmv);
-    const std::string dir = run_dir + "/enhanced_csv/" + stamp;
+    dir = run_dir + "/enhanced_csv/" + stamp;
     mkdirs(dir);
     CHECK(eg_policy_export_improvement_csv(policy, (dir + "/improvement_history.csv").c_str()));
-    if (reduced) { int32_t state = 0; CHECK(eg_fetch_best_run(ctx, &best_run.view, &state)); best_run.valid = state == 1; }
+  }
+  int64_t best_index = -1;
+  { int32_t state = 0; CHECK(eg_fetch_best_result(ctx, &best_run.view, &state, &best_index)); best_run.valid = state == 1; }
+  if (best_run.valid) {   // multi_simulation.rs:821-850
+    const double* bm = best_run.metrics.data();
+    std::printf("BEST SIMULATION RESULTS SUMMARY (iteration %lld)\nFinal net emissions: %.2f tonnes\nEmissions Status: %s\nAverage public opinion: %.1f%%\n"
+                "Total cost: EUR %.2f billion accumulated\nPower reliability: %.1f%%\n", (long long)best_index, bm[0],
+                bm[0] <= 0.0 ? "NET ZERO ACHIEVED" : "NET ZERO NOT ACHIEVED", bm[1] * 100.0, bm[2] / 1e9, bm[3] * 100.0);
+  }
+  if (a.enable_csv_export) {
     if (best_run.valid) {
       CHECK(eg_export_summary_csv(&best_run.view, (dir + "/simulation_summary.csv").c_str(), stamp));
       std::vector<const char*> names;
       for (const std::string& n : wd.names) names.push_back(n.c_str());
       CHECK(eg_export_run_details(&world, names.size() == wd.sx.size() ? names.data() : nullptr, &best_run.view, dir.c_str(), a.seed));
-    } else std::puts("note: no improvement in this run; simulation_summary.csv and the detail files not written");
+    } else std::puts("note: no iteration finished in this run; simulation_summary.csv and the detail files not written");
   }
   std::printf("Done: %llu iterations in %s (%u episodes failed); best_weights.json, latest_weights.json, checkpoint_iteration.txt written\n",
               (unsigned long long)done, run_dir.c_str(), unsigned(eg_policy_get_scalar(policy, 13)) + failed_sequential);

@@ -19,6 +19,7 @@ constexpr int kMults = 3;
 constexpr int kOffsetTypes = 4;
 constexpr int kPsStride = 2624;   // sorted candidate lists on the device: 41 chunks of 64 (2601 -> 2624 entries)
 constexpr int kDrCompact = 352;      // doubles of the compact factor table (the reference's six radii need 333)
+constexpr int kLdsGens = EG_ONCHIP_GENS;      // generators / offsets of an episode that the kernels keep in LDS; the long-replay variant goes on in the episode's record
 constexpr int kShortReplayMax = 96;   // actions in the best list up to which replay episodes stay on the exact scan (eg_rollout.hip, k_rollout kinds)
 constexpr int kMaxVariants = 12;  // distinct (radius class, marine) pairs over the 15 types (8 for the reference's types)
 
@@ -216,7 +217,7 @@ constexpr size_t yearly = n_act + 4 * EG_YEARS;       // f64 [26][21]
 constexpr size_t run_log = yearly + 8 * EG_YEARS * EG_YEARLY_FIELDS;
 constexpr size_t def_log = run_log + EG_RUN_CAP;
 constexpr size_t act_log = def_log + EG_DEF_CAP;
-constexpr size_t gen_cell = act_log + EG_ACT_CAP;     // u16 [512]
+constexpr size_t gen_cell = act_log + EG_ACT_CAP;     // u16 [EG_MAX_GENS]
 constexpr size_t gen_pack = gen_cell + 2 * EG_MAX_GENS;
 constexpr size_t off_pack = gen_pack + 2 * EG_MAX_GENS;
 constexpr size_t stride = (off_pack + 2 * EG_MAX_OFFSETS + 63) & ~size_t(63);
@@ -292,5 +293,12 @@ struct UpdateCandidate {
 };
 static_assert(sizeof(UpdateCandidate) == EG_CANDIDATE_BYTES, "candidate layout is part of the C ABI");
 int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCandidate* d_cand, void* stream);
+// The reference's `best_result` fold (core/multi_simulation.rs:613-620; eg_rollout.hip k_fold_best): the held run's metrics, global
+// index and — kFoldRecord bytes behind the state — its whole record (rec:: layout).
+struct FoldState { double metrics[4]; long long index; int32_t has, pad; };
+constexpr size_t kFoldRecord = 64;
+constexpr size_t kFoldBytes = kFoldRecord + rec::stride;
+static_assert(sizeof(FoldState) <= kFoldRecord, "fold state layout");
+int launch_fold_best(const DevOut& o, uint32_t n, uint64_t first_index, bool cost_only, uint8_t* d_fold, void* stream);
 
 }  // namespace eg

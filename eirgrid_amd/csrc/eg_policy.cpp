@@ -95,6 +95,18 @@ double eg_score_metrics(const double m[4], int32_t cost_only) {   // ai/metrics/
   return 1.0 + (cost_score * cost_weight + m[1] * opinion_weight);
 }
 
+double eg_evaluate_action_impact(const double cur[4], const double nxt[4], int32_t cost_only) {   // ai/metrics/scoring.rs:46-85
+  // SimulationMetrics -> ActionResult as core/multi_simulation.rs:55-62 maps them: net emissions [0], opinion [1], total cost [2]
+  if (cost_only) { const double cost_change = nxt[2] - cur[2]; return -cost_change / std::fmax(std::fabs(cur[2]), 1.0); }
+  if (cur[0] > 0.0) return (cur[0] - nxt[0]) / std::fmax(std::fabs(cur[0]), 1.0);
+  const double cost_change = nxt[2] - cur[2];
+  const double cost_improvement = -cost_change / std::fmax(std::fabs(cur[2]), 1.0);
+  const double opinion_improvement = (nxt[1] - cur[1]) / std::fmax(std::fabs(cur[1]), 1.0);
+  const double cost_weight = cur[2] > kMaxCost * 8.0 ? 0.8 : 0.5;
+  const double opinion_weight = 1.0 - cost_weight;
+  return cost_improvement * cost_weight + opinion_improvement * opinion_weight;
+}
+
 eg_policy* eg_policy_new(void) {   // core.rs:25-250
   eg_policy* p = new eg_policy();
   for (int y = 0; y < Y; ++y) {

@@ -84,9 +84,9 @@ struct __align__(16) Smem {
   uint32_t rng[64];                   // ChaCha12 output buffer: four blocks
   uint32_t rng_key[8];                // ChaCha12 key of the episode stream
   unsigned long long rng_counter;     // next block counter
-  uint16_t gcell[EG_MAX_GENS];        // cell | type << 12
-  uint16_t opack[EG_MAX_OFFSETS];     // type | year << 4 | mult << 9
-  uint8_t gbm[EG_MAX_GENS];           // build-year index | mult << 5
+  uint16_t gcell[kLdsGens];           // cell | type << 12      (the first kLdsGens generators / offsets of the episode: all of them,
+  uint16_t opack[kLdsGens];           // type | year << 4 | mult << 9     except in the long-replay variant, whose lists go on in
+  uint8_t gbm[kLdsGens];              // build-year index | mult << 5     the episode's record in HBM — ListTail)
   uint8_t ydef[192];                  // [0,128) this year's deficit actions (success bonus, simulation.rs:505-519);
                                       // [128,192) sort permutation of the stalled sampler
   // helper waves (small-batch kernel only): search command (double-buffered by sequence parity), results, flags
@@ -110,7 +110,7 @@ static_assert(sizeof(Smem) <= 7 * 1280, "sixteen episodes per CU");
 __shared__ Smem sm;
 // Extra LDS of the small-batch kernel only (it is not referenced by the throughput kernel, so it costs that one nothing).
 struct __align__(16) SmemLatency {
-  int gpk[EG_MAX_GENS + 16];                        // (4 gi, 4 gj) as two int16 per generator of the episode; padding beyond the list
+  int gpk[kLdsGens + 16];                           // (4 gi, 4 gj) as two int16 per generator of the episode; padding beyond the list
   double dr16[kRadiusClasses * kD2Stride * 2];      // the factor table at a stride of 16 bytes (see chunk_product_latency)
 };
 __shared__ SmemLatency sl;
@@ -275,7 +275,7 @@ __device__ __forceinline__ int throughput_table(int info) {
 }
 // small-batch kernel: the generator list starts as padding everywhere; the factor table goes in at a stride of 16 bytes
 __device__ __forceinline__ void load_latency_tables(const DevTables& T, int lane) {
-  for (int i = lane; i < EG_MAX_GENS + 16; i += kWave) sl.gpk[i] = kGenPad4;
+  for (int i = lane; i < kLdsGens + 16; i += kWave) sl.gpk[i] = kGenPad4;
   for (int i = lane; i < kRadiusClasses * kD2Stride; i += kWave) sl.dr16[2 * i] = 1.0;
   for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
     const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
@@ -592,6 +592,26 @@ __device__ __forceinline__ ChunkBest chunk_reduce(double s, int cell, double m03
 // Workgroup barrier that orders LDS only: the episode's output stores and table loads stay in flight across it.
 __device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- lists beyond the on-chip window (long-replay variant only) ------------------------------------------------------
+// The reference's lists are Vecs; a replay episode applies and records every action twice, so in a training loop
+// the replayed lists double whenever a replay episode becomes the best strategy: 468 generators after seven updates, 965
+// actions in the best list soon after at larger batches.  The first kLdsGens generators / offsets of an episode live in LDS
+// (gcell / gbm / opack); a long-replay episode that grows past that goes on in its own output record — it appends every
+// generator and offset there anyway (gen_cell / gen_pack / off_pack, EG_MAX_GENS entries) — and reads those entries back in
+// blocks of 64 wherever a list is walked: the year-start folds, the exact product of a candidate, a field that joins, the
+// exact scan.  Blocks start at multiples of 64 and kLdsGens is one, so a block is either all window or all tail.
+// The entries were stored by this wave itself: they are read past the CU's L1 (agent scope), like the penalty field.
+struct ListTail { unsigned long long gen_cell, gen_pack, off_pack; };      // addresses: they cross non-inlined calls as integers
+typedef unsigned short __attribute__((address_space(1)))* GlobalU16;
+__device__ __forceinline__ int tail_u16(unsigned long long addr, int i) {
+  return (int)__hip_atomic_load((GlobalU16)addr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// cell of generator g (a lane each), from the window or from the record; `far`: what a lane beyond the list gets
+__device__ __forceinline__ int list_cell(unsigned long long tail_cells, int gb, int lane, int ngen_s, int far) {
+  if (gb + lane >= ngen_s) return far;
+  return gb < kLdsGens ? (int)(sm.gcell[gb + lane] & 0xFFF) : tail_u16(tail_cells, gb + lane);
+}
+
 // ---- aggregates at the start of a year: existing plant first (host tables), then every generator in list order.
 //      The lanes gather the per-generator terms in parallel (year_gather: requests only); the sums are then folded lane
 //      by lane with readlane, i.e. in list order (year_fold).  Output / CO2 terms of a plant never change (delays off),
@@ -616,6 +636,23 @@ __device__ __forceinline__ void year_gather_offsets(const DevTables& T, int lane
   const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
   t.o_v = T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + b]; t.o_c = T.offc()[((unsigned)yi * kOffsetTypes + ot) * kMults + m];
 }
+// the same requests for a block of the list's tail (long-replay variant): the entries come from the episode's record
+__device__ __forceinline__ void year_gather_gens_tail(const DevTables& T, int lane, int yi, int base, int ngen_s, YearTerms& t, const ListTail& tail) {
+  const double* ccy = T.cc() + (unsigned)yi * kTypes * kYears * kMults * 2;
+  const int g = base + lane;
+  const bool valid = g < ngen_s;
+  const int cell = valid ? tail_u16(tail.gen_cell, g) : 0, pk = valid ? tail_u16(tail.gen_pack, g) : 0;      // type | build year << 4 | mult << 9
+  const int b = (pk >> 4) & 31, m = pk >> 9;
+  t.g_t = pk & 15;
+  t.g_cc = *reinterpret_cast<const double2*>(ccy + ((unsigned)(t.g_t * kYears + b) * kMults + m) * 2);
+  t.g_m03 = T.m03()[cell]; t.g_t12 = T.t12()[(unsigned)yi * kTypes + t.g_t];
+}
+__device__ __forceinline__ void year_gather_offsets_tail(const DevTables& T, int lane, int yi, int base, int noff_s, YearTerms& t, const ListTail& tail) {
+  const int k = base + lane;
+  const int p = k < noff_s ? tail_u16(tail.off_pack, k) : 0;
+  const int ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+  t.o_v = T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + b]; t.o_c = T.offc()[((unsigned)yi * kOffsetTypes + ot) * kMults + m];
+}
 // the first 64 entries of each list are requested here; year_fold gathers the rest (rare) itself
 __device__ __forceinline__ YearTerms year_gather(const DevTables& T, int lane, int yi, int ngen_s, int noff_s) {
   YearTerms t; t.g_cc.x = 0.0; t.g_cc.y = 0.0; t.g_m03 = 0.0; t.g_t12 = 0.0; t.o_v = 0.0; t.o_c = 0.0; t.g_t = 0;
@@ -624,10 +661,15 @@ __device__ __forceinline__ YearTerms year_gather(const DevTables& T, int lane, i
   return t;
 }
 // `s` comes in holding the starting values (0 / the existing-plant prefix) and leaves holding the year-start sums
+// kLong (long-replay variant): blocks beyond the on-chip window come from the episode's record (`tail`)
+template <bool kLong>
 __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, int ngen_s, int noff_s, bool carry, YearTerms t,
-                                          YearSums& s) {
+                                          YearSums& s, const ListTail& tail) {
   for (int base = 0; base < ngen_s; base += kWave) {
-    if (base > 0) year_gather_gens(T, lane, yi, base, ngen_s, t);      // beyond the first 64 generators (rare)
+    if (base > 0) {      // beyond the first 64 generators (rare)
+      if (kLong && base >= kLdsGens) year_gather_gens_tail(T, lane, yi, base, ngen_s, t, tail);
+      else year_gather_gens(T, lane, yi, base, ngen_s, t);
+    }
     const double2 cc = t.g_cc;
     const int ty = t.g_t;
     const double op = (t.g_m03 + t.g_t12) + cc.y;
@@ -655,7 +697,10 @@ __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, 
     s.opcnt += cnt;
   }
   for (int base = 0; base < noff_s; base += kWave) {
-    if (base > 0) year_gather_offsets(T, lane, yi, base, noff_s, t);
+    if (base > 0) {
+      if (kLong && base >= kLdsGens) year_gather_offsets_tail(T, lane, yi, base, noff_s, t, tail);
+      else year_gather_offsets(T, lane, yi, base, noff_s, t);
+    }
     const double ov = t.o_v, oc = t.o_c;
     const int cnt = noff_s - base < kWave ? noff_s - base : kWave;
     for (int j = 0; j < cnt; ++j) { s.offs += readlane_f64(ov, j); s.ocost += readlane_f64(oc, j); }
@@ -1041,26 +1086,32 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
 // A class joins: its field = for every cell the product of the factors of the generators placed so far (any order: the
 // field only serves a bound).  The field of the 41 blocks of 64 cells sits in registers while the generators pass by; a
 // generator only touches the blocks whose rows come within `reach` of its own row (a scalar test per block).
+// (`tail_cells`: the cells of the generators beyond the on-chip window, ListTail)
 template <bool kLatency>
-__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, int lane, int rc, int table, int reach, int ngen) {
+__device__ __noinline__ void heavy_build_class(unsigned long long class_addr, unsigned long long tail_cells, int lane, int rc, int table, int reach, int ngen) {
   const GlobalF64 f = (GlobalF64)class_addr;
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double p[kChunks];
   const int cap = factor_cap<kLatency>(table);
+  const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
 #pragma unroll
   for (int ch = 0; ch < kChunks; ++ch) p[ch] = 1.0;
-  for (int g = 0; g < ngen; ++g) {
-    const int gc = __builtin_amdgcn_readfirstlane((int)(sm.gcell[g] & 0xFFF));
-    const int gi = gc / kGrid, gj = gc - gi * kGrid;
-    const int row_lo = gi - reach, row_hi = gi + reach;
+  for (int gb = 0; gb < ngen_s; gb += kWave) {      // the list in blocks of 64, a generator per lane; then one generator at a time
+    const int mine = list_cell(tail_cells, gb, lane, ngen_s, 0);
+    const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+    for (int j = 0; j < cnt; ++j) {
+      const int gc = __builtin_amdgcn_readlane(mine, j);
+      const int gi = gc / kGrid, gj = gc - gi * kGrid;
+      const int row_lo = gi - reach, row_hi = gi + reach;
 #pragma unroll
-    for (int ch = 0; ch < kChunks; ++ch) {
-      if ((ch * kWave + kWave - 1) / kGrid < row_lo || (ch * kWave) / kGrid > row_hi) continue;      // uniform: constants against scalars
-      const int cell = ch * kWave + lane;
-      const int ci = cell / kGrid, cj = cell - ci * kGrid;
-      int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
-      q = q < cap ? q : cap;
-      p[ch] = p[ch] * factor_by_q<kLatency>(rc, table, q);
+      for (int ch = 0; ch < kChunks; ++ch) {
+        if ((ch * kWave + kWave - 1) / kGrid < row_lo || (ch * kWave) / kGrid > row_hi) continue;      // uniform: constants against scalars
+        const int cell = ch * kWave + lane;
+        const int ci = cell / kGrid, cj = cell - ci * kGrid;
+        int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
+        q = q < cap ? q : cap;
+        p[ch] = p[ch] * factor_by_q<kLatency>(rc, table, q);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
@@ -1074,14 +1125,14 @@ __device__ __noinline__ void heavy_build_class(unsigned long long class_addr, in
 // fed by v_readlane.  The winner of a search is a cell that few generators reach: a handful of multiplications instead
 // of one per generator (chunk_product, which evaluates 64 different candidates at once, cannot skip anything).
 template <bool kLatency>
-__device__ __forceinline__ double exact_product_chain(int rc, int table, int ngen_s, double te, int cell, int lane) {
+__device__ __forceinline__ double exact_product_chain(int rc, int table, int ngen_s, double te, int cell, int lane, unsigned long long tail_cells) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   const int cap = factor_cap<kLatency>(table);
   double s = te;
   for (int gb = 0; gb < ngen_s; gb += kWave) {
     double f = 1.0;
     if (gb + lane < ngen_s) {
-      const int gc = (int)(sm.gcell[gb + lane] & 0xFFF);
+      const int gc = list_cell(tail_cells, gb, lane, ngen_s, 0);
       const int gi = gc / kGrid, gj = gc - gi * kGrid;
       int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
       q = q < cap ? q : cap;
@@ -1099,7 +1150,7 @@ __device__ __forceinline__ double exact_product_chain(int rc, int table, int nge
 // `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
 // returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
 template <bool kLatency>
-__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, double size_factor, int lane, int rc, int tbl, int ngen) {
+__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, unsigned long long tail_cells, double size_factor, int lane, int rc, int tbl, int ngen) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1188,13 +1239,14 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   if (ncand == 1 && solo >= 0) {      // the usual case: one candidate, its record still in the lane that found it
     const double te1 = readlane_f64(q1te, solo), cf1 = readlane_f64(q1cf, solo);
     const int cell1 = __builtin_amdgcn_readlane(q1cell, solo);
-    b.score = (exact_product_chain<kLatency>(rc, tbl, ngen_s, te1, cell1, lane) * cf1) * size_factor;
+    b.score = (exact_product_chain<kLatency>(rc, tbl, ngen_s, te1, cell1, lane, tail_cells) * cf1) * size_factor;
     b.cell = cell1; b.m03 = readlane_f64(q1m03, solo);
-  } else if (ncand <= 4) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
+  } else if (ncand <= 4 || ngen_s > kLdsGens) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
+                                                     // (chunk_product below walks the on-chip window only)
     for (int k = 0; k < ncand; ++k) {
       const int rk = __builtin_amdgcn_readfirstlane(sm.gstage[1][k]);
       const PsRec e = load_rec(list_addr, rk);      // the same record in every lane
-      const double sk = (exact_product_chain<kLatency>(rc, tbl, ngen_s, e.te, (int)e.cell, lane) * e.cf) * size_factor;
+      const double sk = (exact_product_chain<kLatency>(rc, tbl, ngen_s, e.te, (int)e.cell, lane, tail_cells) * e.cf) * size_factor;
       if (sk > b.score || (sk == b.score && sk > 0.0 && (int)e.cell < b.cell)) { b.score = sk; b.cell = (int)e.cell; b.m03 = e.m03; }
     }
   } else {               // many ties: 64 candidates at once (chunk_product)
@@ -1215,6 +1267,50 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   // requested, in units of 2 KB (= a chunk of 64 records): the K chunks scanned and the winner's chunk (a second pass re-reads
   // the first pass's records) and K x 64 field entries of 8 B (the field update that follows bills itself)
   return b.cell | ((K + 1 + (K + 3) / 4) << 16);
+}
+
+// The exact scan for a list that has outgrown the on-chip window (long-replay variant; reached when the field path cannot
+// decide: no field slot, scores in subnormal territory, ties en masse).  The candidates, their order, the stop rule and the tie
+// rule are place_search's; the generators stream past in blocks of 64 (the window from LDS, the rest from the episode's record)
+// and every lane folds all of them, in list order, for its own candidate: a v_readlane per generator and chunk.  Slow, and rare.
+// returns cell | chunks requested << 16, or -1 (no candidate with a positive score: actions.rs:77-89); the winner's 0.03 * mean
+// settlement opinion in sm.hres[1].m03
+template <bool kLatency>
+__device__ __noinline__ int place_exact_long(unsigned long long list_addr, unsigned long long tail_cells, double size_factor, int lane, int rc, int tbl, int ngen) {
+  const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
+  const int cap = factor_cap<kLatency>(tbl);
+  constexpr int kChunks = (kCells + kWave - 1) / kWave;
+  double best = 0.0, m03w = 0.0; int best_c = kCells, chunks = 0;
+  for (int chunk = 0; chunk < kChunks; ++chunk) {
+    const int r = chunk * kWave + lane;
+    const PsRec c = load_rec(list_addr, r);
+    const double base = (c.te * c.cf) * size_factor;      // (te = 0 beyond the 2601 candidates)
+    if (chunk > 0 && !(readlane_f64(base, 0) >= best)) break;      // sorted descending: lane 0 holds the chunk's bound
+    ++chunks;
+    const int ci = (int)c.cell / kGrid, cj = (int)c.cell - ci * kGrid;
+    double s = c.te;
+    for (int gb = 0; gb < ngen_s; gb += kWave) {
+      const int mine = list_cell(tail_cells, gb, lane, ngen_s, 0);
+      const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+      for (int j = 0; j < cnt; ++j) {
+        const int gc = __builtin_amdgcn_readlane(mine, j);
+        const int gi = gc / kGrid, gj = gc - gi * kGrid;
+        int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
+        q = q < cap ? q : cap;      // (the table holds 1.0 there, and x * 1.0 == x)
+        s = s * factor_by_q<kLatency>(rc, tbl, q);
+      }
+    }
+    s = (s * c.cf) * size_factor;
+    s = r < kCells ? s : 0.0;
+    if (__any(s > best || (s == best && s > 0.0 && (int)c.cell < best_c))) {
+      const ChunkBest b = chunk_reduce<false>(s, (int)c.cell, c.m03);
+      if (b.score > best || (b.score == best && b.cell < best_c)) { best = b.score; best_c = b.cell; m03w = b.m03; }
+    }
+  }
+  wave_sync();
+  if (lane == 0) sm.hres[1].m03 = m03w;
+  wave_sync();
+  return best > 0.0 ? (best_c | (chunks << 16)) : -1;
 }
 
 // ---- weight nudges -----------------------------------------------------------------------------------------
@@ -1507,6 +1603,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   uint16_t* gen_cell = O.gen_cell(e);
   uint16_t* gen_pack = O.gen_pack(e);
   uint16_t* off_pack = O.off_pack(e);
+  // the long-replay variant's lists go on in the record beyond the on-chip window (ListTail); the others end there
+  const ListTail tail = {(unsigned long long)gen_cell, (unsigned long long)gen_pack, (unsigned long long)off_pack};
+  constexpr int kGenCap = kHeavy ? EG_MAX_GENS : kLdsGens, kOffCap = kHeavy ? EG_MAX_OFFSETS : kLdsGens;
+  bool helper_sums = kHelpers > 0;      // (long-replay variant: until a list outgrows the window — the helper only reads LDS)
 
   // Wave-uniform doubles that are written once a year and read once a year live in LDS, not in (64-lane) registers:
   // sm.acc[0..2] accumulators of metrics_calculation.rs:133-153, [3..6] last yearly row; sm.yend[0..5] last year's
@@ -1526,7 +1626,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     const int ngen_s = __builtin_amdgcn_readfirstlane(ep.ngen);
     const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
     const bool carry = ((carry_mask >> yi) & 1u) != 0u;
-    const bool sums_from_helper = kHelpers > 0 && yi > 0;
+    const bool sums_from_helper = kHelpers > 0 && yi > 0 && (!kHeavy || helper_sums);
     YearTerms terms;
     if (!sums_from_helper) terms = year_gather(T, lane, yi, ngen_s, noff_s);
     {  // this year's policy block -> LDS (requested a year ahead), then request next year's
@@ -1563,7 +1663,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         ys.co2 = sm.ysum[4]; ys.tg = sm.ysum[5]; ys.ig = sm.ysum[6]; ys.sg = sm.ysum[7]; ys.opcnt = sm.ysum_opcnt;
       } else {
         ys = year_sums_init_current();
-        year_fold(T, lane, yi, ngen_s, noff_s, carry, terms, ys);
+        year_fold<kHeavy>(T, lane, yi, ngen_s, noff_s, carry, terms, ys, tail);
       }
       a.gcost = ys.gcost; a.optot = ys.optot; a.offs = ys.offs; a.ocost = ys.ocost; a.opcnt = ys.opcnt;
       if (carry) { a.co2 = sm.yend[2]; a.tg = sm.yend[3]; a.ig = sm.yend[4]; a.sg = sm.yend[5]; }
@@ -1712,7 +1812,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             const int hv = info & 15, hrc = (info >> 4) & 15;
             const unsigned long long class_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * slot_bytes + (unsigned long long)(hrc * kFieldStride) * 8ull;
             if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
-              heavy_build_class<(kHelpers > 0)>(class_addr, lane, hrc, throughput_table(info), (info >> 8) & 15, ep.ngen);
+              heavy_build_class<(kHelpers > 0)>(class_addr, tail.gen_cell, lane, hrc, throughput_table(info), (info >> 8) & 15, ep.ngen);
               ep.heavy_classes |= 1 << hrc;
               ep.heavy_quads = heavy_pack_list<(kHelpers > 0)>((unsigned long long)(T.base + tab::hv_box), (unsigned long long)(T.base + tab::dr_meta), lane, ep.heavy_classes);
             }
@@ -1720,7 +1820,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             const unsigned long long th0 = __builtin_readcyclecounter();
 #endif
             const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride), class_addr,
-                                                        T.size_factor, lane, hrc, throughput_table(info), ep.ngen);
+                                                        tail.gen_cell, T.size_factor, lane, hrc, throughput_table(info), ep.ngen);
 #ifdef EG_STAMPS
             const unsigned long long th1 = __builtin_readcyclecounter();
             stamps[9] += th1 - th0;
@@ -1730,6 +1830,14 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             stamps[10] += __builtin_readcyclecounter() - th1;
 #endif
           }
+        }
+        if constexpr (kHeavy) if (!placed && ep.ngen > kLdsGens) {      // the exact scan, for a list beyond the window (place_search walks LDS)
+          const int info = __builtin_amdgcn_readfirstlane(sm.type_info[t]);
+          const int xr = place_exact_long<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + (info & 15)) * kPsStride), tail.gen_cell,
+                                                          T.size_factor, lane, (info >> 4) & 15, throughput_table(info), ep.ngen);
+          cell = xr < 0 ? -1 : (xr & 0xFFFF);
+          if (xr >= 0) { ep.chunks += xr >> 16; m03v = sm.hres[1].m03; }
+          placed = true; between();
         }
         if (!placed) {
 #ifdef EG_STAMPS
@@ -1742,10 +1850,12 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         EG_T1(1);
         if (cell < 0) { ep.status = cell == kSearchLost ? EG_EP_INTERNAL : EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         EG_MARKG(21);
-        if (ep.ngen >= EG_MAX_GENS) { ep.status = EG_EP_OVERFLOW; break; }
+        if (ep.ngen >= kGenCap) { ep.status = EG_EP_OVERFLOW; break; }
         if (lane == 0) {
-          sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
-          sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
+          if (!kHeavy || ep.ngen < kLdsGens) {
+            sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
+            sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
+          }
           gen_cell[ep.ngen] = (uint16_t)cell;
           gen_pack[ep.ngen] = (uint16_t)(t | (yi << 4) | (m << 9));
         }
@@ -1772,7 +1882,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
-          if (lane == 0) {
+          if (lane == 0 && (!kHeavy || ep.ngen <= kLdsGens)) {
             const int gi = cell / kGrid;
             sl.gpk[ep.ngen - 1] = (4 * gi) | ((4 * (cell - gi * kGrid)) << 16);
           }
@@ -1781,9 +1891,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
       } else if (action < kFirstOther) {
         EG_MARKG(20);
         const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
-        if (ep.noff >= EG_MAX_OFFSETS) { ep.status = EG_EP_OVERFLOW; break; }
+        if (ep.noff >= kOffCap) { ep.status = EG_EP_OVERFLOW; break; }
         const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9));
-        if (lane == 0) { sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
+        if (lane == 0) { if (!kHeavy || ep.noff < kLdsGens) sm.opack[ep.noff] = p; off_pack[ep.noff] = p; }
         wave_sync();
         ep.noff += 1;
         a.offs += T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + yi];
@@ -1830,8 +1940,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     }
     if (ep.status != EG_EP_OK) break;
     ep.bytes += 2ull * (unsigned long long)(ep.n_act_y + ep.n_def_y);
+    if constexpr (kHelpers > 0 && kHeavy) if (ep.ngen > kLdsGens || ep.noff > kLdsGens) helper_sums = false;
     if constexpr (kHelpers > 0) {      // the lists are final for this year: the helper folds next year's starting sums meanwhile
-      if (yi + 1 < kYears) {
+      if (yi + 1 < kYears && (!kHeavy || helper_sums)) {
         search_seq += 1; year_seq = search_seq;
         if (lane == 0) {
           sm.cmd[search_seq & 1][0] = kCmdYear | (yi + 1) | ((int)((carry_mask >> (yi + 1)) & 1u) << 8) | ((int)((carry_mask >> (yi + 2)) & 1u) << 9);
@@ -2043,6 +2154,77 @@ __global__ void __launch_bounds__(1024) k_pick_best(DevOut O, uint32_t n, unsign
   if (tid < EG_YEARS) { cand->n_run[tid] = O.n_run(win)[tid]; cand->n_def[tid] = O.n_def(win)[tid]; }
   for (int i = tid; i < EG_RUN_CAP; i += 1024) cand->run_log[i] = O.run_log(win)[i];
   for (int i = tid; i < EG_DEF_CAP; i += 1024) cand->def_log[i] = O.def_log(win)[i];
+}
+
+// ---- the reference's `best_result` (core/multi_simulation.rs:384, :613-620): which run is summarised and exported ------
+// After its parallel section the reference folds the results in iteration order:
+//     best_result = None;  for result in results { if best_result.map_or(true, |best|
+//         evaluate_action_impact(result.metrics -> best.metrics, optimization_mode) > 0.0) { best_result = Some(result) } }
+// with the arguments as written — `result` is the "current state" and `best` the "new state", so a result takes over when
+// the held one is an IMPROVEMENT on it.  That is the run multi_simulation.rs:821-905 prints and exports, and it is not the
+// policy's best strategy (score_metrics, strategy.rs:19-258).  The fold is sequentially dependent but a result rarely takes
+// over (the held run drifts towards the worst: a running extreme), so it is evaluated speculatively: 1024 results at a time
+// against the held run, the FIRST that takes over (lowest index) becomes the held run and the rest of the window is
+// examined again — the sequential fold's answer, in n / 1024 + (take-overs) rounds.  Failed episodes are skipped (in the
+// reference a failed iteration ends the run, multi_simulation.rs:611).  The winner's whole record is kept behind the state.
+__device__ __forceinline__ double fold_impact(const double* cur, const double* nxt, int cost_only) {      // scoring.rs:46-85
+  State c, x;
+  c.net = cur[0]; c.opinion = cur[1]; c.balance = 0.0; c.cost = cur[2];      // metrics_to_action_result, multi_simulation.rs:55-62
+  x.net = nxt[0]; x.opinion = nxt[1]; x.balance = 0.0; x.cost = nxt[2];
+  if (cost_only) { const double cost_change = x.cost - c.cost; return -cost_change / dmax(dabs(c.cost), 1.0); }      // scoring.rs:52-58
+  return evaluate_impact(c, x);
+}
+__global__ void __launch_bounds__(1024) k_fold_best(DevOut O, uint32_t n, unsigned long long first_index, int cost_only, uint8_t* fold) {
+  constexpr int kPer = 8;      // results per thread and tile, in registers
+  __shared__ double s_best[4];
+  __shared__ int s_has, s_first, s_win;
+  const int tid = threadIdx.x;
+  FoldState* st = reinterpret_cast<FoldState*>(fold);
+  if (tid < 4) s_best[tid] = st->metrics[tid];
+  if (tid == 0) { s_has = st->has; s_win = -1; s_first = 0x7FFFFFFF; }
+  __syncthreads();
+  for (uint32_t tile = 0; tile < n; tile += kPer * 1024u) {
+    double m[kPer][4]; bool ok[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const uint32_t i = tile + (uint32_t)k * 1024u + (uint32_t)tid;
+      ok[k] = i < n && *O.status(i) == EG_EP_OK;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[k][j] = ok[k] ? O.metrics(i)[j] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {      // window k: results tile + 1024 k + [0, 1024), in index order = thread order
+      int from = 0;
+      for (;;) {
+        double b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = s_best[j];
+        const bool take = tid >= from && ok[k] && (s_has == 0 || fold_impact(m[k], b, cost_only) > 0.0);
+        if (take) atomicMin(&s_first, tid);
+        __syncthreads();
+        const int f = s_first;
+        __syncthreads();      // everybody has read it
+        if (f == 0x7FFFFFFF) break;
+        if (tid == f) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s_best[j] = m[k][j];
+          s_has = 1; s_win = (int)(tile + (uint32_t)k * 1024u) + f; s_first = 0x7FFFFFFF;
+        }
+        from = f + 1;
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  const int win = s_win;
+  if (win < 0) return;      // the held run stays
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(O.base + (size_t)win * rec::stride);
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(fold + kFoldRecord);
+  for (int i = tid; i < (int)(rec::stride / 8); i += 1024) dst[i] = src[i];
+  if (tid == 0) {
+    for (int j = 0; j < 4; ++j) st->metrics[j] = s_best[j];
+    st->index = (long long)(first_index + (unsigned long long)win); st->has = 1;
+  }
 }
 
 // ---- on-device batch update (eg_policy_apply_reduced, eg_policy.cpp, restated for one 1024-thread workgroup) -----------
@@ -2420,6 +2602,11 @@ int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, l
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_update_stats, dim3(n), dim3(kWave), 0, (hipStream_t)stream, o, s, n, d_stats);
+  return (int)hipGetLastError();
+}
+int launch_fold_best(const DevOut& o, uint32_t n, uint64_t first_index, bool cost_only, uint8_t* d_fold, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fold_best, dim3(1), dim3(1024), 0, (hipStream_t)stream, o, n, (unsigned long long)first_index, cost_only ? 1 : 0, d_fold);
   return (int)hipGetLastError();
 }
 int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCandidate* d_cand, void* stream) {

@@ -169,6 +169,12 @@ def apply_packet(weights: "ActionWeights", stats, candidates, noise_seed: int = 
     return rc == 1
 
 
+def evaluate_action_impact(current_metrics, new_metrics, cost_only: bool = False) -> float:
+    """ai/metrics/scoring.rs:46-85 on SimulationMetrics quadruples (metrics_to_action_result, multi_simulation.rs:55-62)."""
+    a = np.ascontiguousarray(current_metrics, dtype=np.float64); b = np.ascontiguousarray(new_metrics, dtype=np.float64)
+    return N.lib().eg_evaluate_action_impact(_p(a, C.c_double), _p(b, C.c_double), int(cost_only))
+
+
 def score_metrics(metrics, cost_only: bool = False) -> float:
     m = np.ascontiguousarray(metrics, dtype=np.float64)
     return N.lib().eg_score_metrics(_p(m, C.c_double), int(cost_only))
@@ -394,6 +400,19 @@ class Engine:
         state = C.c_int32(0)
         N.check(N.lib().eg_fetch_best_run(self.h, C.byref(out), C.byref(state)), "eg_fetch_best_run")
         return state.value, (res if state.value == 1 else None)
+
+    def track_best_result(self, cost_only: bool = False, on: bool = True) -> None:
+        """Start the reference's `best_result` fold at None (core/multi_simulation.rs:384, :613-620): every batch launched from
+        now on is folded on the device in iteration order (eg_best_result_track)."""
+        N.check(N.lib().eg_best_result_track(self.h, 0 if not on else (2 if cost_only else 1)), "eg_best_result_track")
+
+    def fetch_best_result(self):
+        """(global index, record) of the run the reference would summarise and export, or (None, None) before any result."""
+        res = BatchResult.alloc(1)
+        out = res.struct()
+        state = C.c_int32(0); index = C.c_int64(-1)
+        N.check(N.lib().eg_fetch_best_result(self.h, C.byref(out), C.byref(state), C.byref(index)), "eg_fetch_best_result")
+        return (int(index.value), res) if state.value == 1 else (None, None)
 
     def fetch_scores(self, n_episodes: int) -> np.ndarray:
         s = np.zeros(n_episodes)

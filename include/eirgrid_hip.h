@@ -50,12 +50,19 @@ extern "C" {
 #define EG_CELLS (EG_GRID * EG_GRID)
 #define EG_YEARLY_FIELDS 21
 
-/* per-episode capacities of the device logs (an episode that exceeds one ends with status EG_EP_OVERFLOW) */
-#define EG_MAX_GENS 512
-#define EG_MAX_OFFSETS 512
-#define EG_RUN_CAP 2048
-#define EG_DEF_CAP 1024
-#define EG_ACT_CAP 1024
+/* Per-episode capacities of the records (an episode that exceeds one ends with status EG_EP_OVERFLOW).  The reference's lists
+ * are Vecs (core/simulation.rs:146-162, :406-409; ai/learning/weights/sampling.rs:93-101, :258-266); a replay episode records and
+ * applies every action twice, so the lists of a training loop double with every replay episode that becomes the
+ * best strategy.  Episodes that replay a long best list (more than 96 actions) run a kernel variant whose lists continue in the
+ * episode's own record beyond the on-chip window, up to these capacities — the same 4096 the CPU oracle stops at
+ * (oracle/eg_oracle.h OG_LOG_CAP).  Sampled episodes and replays of a short list stay within the on-chip window of
+ * EG_ONCHIP_GENS generators / offsets (they place 25-200). */
+#define EG_MAX_GENS 4096
+#define EG_MAX_OFFSETS 4096
+#define EG_RUN_CAP 4096
+#define EG_DEF_CAP 4096
+#define EG_ACT_CAP 4096
+#define EG_ONCHIP_GENS 512
 
 #define EG_OK 0
 #define EG_ERR_NO_DEVICE (-1)
@@ -201,12 +208,28 @@ int32_t eg_fetch_episode_lists(eg_ctx *, uint32_t episode, double metrics[4], in
 
 /* Full record of ONE episode of the last batch (every non-NULL field of `out`, sized for n = 1). */
 int32_t eg_fetch_record(eg_ctx *, uint32_t episode, eg_episode_out *out);
-/* The reference keeps the SimulationResult of the best episode for its export (multi_simulation.rs:494-508, :852-905).
- * With the policy resident on the device, k_apply_update keeps that episode's record next to the policy whenever an
+/* The record of the episode that is the policy's best strategy (update_best_strategy, ai/learning/weights/strategy.rs:19-258):
+ * with the policy resident on the device, k_apply_update keeps that episode's record next to the policy whenever an
  * update installs a new best strategy.  *state: 0 = no improvement yet, 1 = `out` (n = 1) was filled, 2 = the best
  * episode ran on another rank (ask that rank).  Yearly rows are only meaningful when the policy was pushed with
- * eg_opts.write_yearly = 1. */
+ * eg_opts.write_yearly = 1.  (NOT the run the reference summarises and exports: that is eg_fetch_best_result below.) */
 int32_t eg_fetch_best_run(eg_ctx *, eg_episode_out *out, int32_t *state);
+
+/* The reference's `best_result` (core/multi_simulation.rs:384, :613-620): after its parallel section the reference folds the
+ * results of THIS process's iterations in iteration order,
+ *     if best_result.map_or(true, |best| evaluate_action_impact(&result.metrics, &best.metrics, optimization_mode) > 0.0)
+ *         { best_result = Some(result) }
+ * — arguments as written: `result` is the current state, `best` the new one, so a result takes over when the held run is an
+ * improvement ON it — and that run is what multi_simulation.rs:821-905 prints and exports (simulation_summary.csv, the detail
+ * files).  eg_best_result_track starts the fold at None (mode 1: optimization_mode None, 2: "cost_only" (--cost-only), 0: stop
+ * tracking); from then on every batch launched on this context is folded on the device behind its rollout, in global index
+ * order, failed episodes skipped (in the reference a failed iteration ends the run).  eg_fetch_best_result copies the held
+ * run's record (n = 1; *state 0: none yet, 1: filled; *global_index may be NULL).  One fold per context = per process, as in
+ * the reference; eg_evaluate_action_impact is ai/metrics/scoring.rs:46-85 on SimulationMetrics quadruples
+ * (metrics_to_action_result, multi_simulation.rs:55-62). */
+int32_t eg_best_result_track(eg_ctx *, int32_t mode);
+int32_t eg_fetch_best_result(eg_ctx *, eg_episode_out *out, int32_t *state, int64_t *global_index);
+double eg_evaluate_action_impact(const double current_metrics[4], const double new_metrics[4], int32_t cost_only);
 
 /* Test hook: fills the LDS of every compute unit with `value` and waits.  LDS is not cleared between workgroups, so a
  * kernel that reads a word before writing it sees what the previous tenant left; the parity tests call this with small
@@ -215,7 +238,7 @@ int32_t eg_debug_fill_lds(eg_ctx *, uint32_t value);
 
 /* B2: one placement search on the device (settlements of year index `year_index`, the ctx's existing plant plus
  * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */
-int32_t eg_place(eg_ctx *, int32_t gen_type, int32_t year_index, const uint16_t *extra_cells, int32_t n_extra,
+int32_t eg_place(eg_ctx *, int32_t gen_type, int32_t year_index, const uint16_t *extra_cells, int32_t n_extra /* <= EG_ONCHIP_GENS */,
                  int32_t *out_cell, double *out_score);
 
 /* B2 with the reference's own signature — MetalLocationSearch::find_suitable_location(&self, settlements, generators,

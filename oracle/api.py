@@ -109,6 +109,8 @@ def lib():
     L.og_score_metrics.argtypes = [dp, C.c_int32]
     L.og_evaluate_action_impact.restype = C.c_double
     L.og_evaluate_action_impact.argtypes = [dp, dp, C.c_int32]
+    L.og_fold_best_result.restype = C.c_int32
+    L.og_fold_best_result.argtypes = [C.c_int32, C.POINTER(C.c_int32), dp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), dp, C.POINTER(C.c_int64)]
     L.og_carbon_price.restype = C.c_double
     L.og_carbon_price.argtypes = [C.c_int32]
     L.og_type_power_output.restype = C.c_double
@@ -330,6 +332,24 @@ def score_metrics(metrics, cost_only=False):
 def evaluate_action_impact(cur, nxt, cost_only=False):
     a = np.ascontiguousarray(cur, dtype=np.float64); b = np.ascontiguousarray(nxt, dtype=np.float64)
     return lib().og_evaluate_action_impact(_dp(a), _dp(b), int(cost_only))
+
+
+class BestResultFold:
+    """The reference's `best_result` (core/multi_simulation.rs:384, :613-620), folded batch after batch."""
+
+    def __init__(self, cost_only=False):
+        self.cost_only = bool(cost_only); self.has = C.c_int32(0); self.best = np.zeros(4); self.index = C.c_int64(-1); self.takeovers = 0
+
+    def feed(self, status, metrics, first_index=0):
+        st = np.ascontiguousarray(status, dtype=np.int32); m = np.ascontiguousarray(metrics, dtype=np.float64).reshape(-1, 4)
+        assert len(st) == len(m)
+        self.takeovers += lib().og_fold_best_result(len(st), st.ctypes.data_as(C.POINTER(C.c_int32)), _dp(m), int(self.cost_only), int(first_index),
+                                                    C.byref(self.has), _dp(self.best), C.byref(self.index))
+        return self
+
+    @property
+    def winner(self):
+        return int(self.index.value) if self.has.value else None
 
 
 def chacha_block(key_words, counter, stream, rounds):

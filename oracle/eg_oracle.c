@@ -807,6 +807,23 @@ double og_evaluate_action_impact(const double c[4], const double n[4], int32_t c
   return evaluate_impact(&a, &b);
 }
 
+/* core/multi_simulation.rs:613-620 with metrics_to_action_result of :55-62 (power_balance: 0.0) */
+int32_t og_fold_best_result(int32_t n, const int32_t *status, const double *metrics, int32_t cost_only, int64_t first_index,
+                            int32_t *has, double best[4], int64_t *best_index) {
+  int32_t takeovers = 0;
+  for (int32_t i = 0; i < n; ++i) {
+    if (status && status[i] != 0) continue; /* (a failed iteration ends the reference's run, :611) */
+    const double *m = metrics + 4 * (size_t)i;
+    int take = 1;
+    if (*has) {
+      double result_ar[4] = {m[0], m[1], 0.0, m[2]}, best_ar[4] = {best[0], best[1], 0.0, best[2]};
+      take = og_evaluate_action_impact(result_ar, best_ar, cost_only) > 0.0;
+    }
+    if (take) { for (int k = 0; k < 4; ++k) best[k] = m[k]; *has = 1; *best_index = first_index + i; takeovers += 1; }
+  }
+  return takeovers;
+}
+
 /* learning.rs:21-88.  `relative_improvement` compares the best score with itself (Q4) and is therefore 0 whenever the
  * best score is positive; otherwise it equals that (non-positive) score.  The optimisation mode held inside
  * ActionWeights is always None (Q3). */

@@ -129,6 +129,14 @@ int32_t og_reduced_batch_update(og_weights *shared, int32_t n, const int32_t *st
                                 const uint8_t *def_log, int32_t def_stride, uint64_t noise_seed, int64_t *stats_out,
                                 int32_t *winner_out);
 
+/* The reference's choice of the run it summarises and exports (core/multi_simulation.rs:384, :613-620): a left fold over the
+ * results of the process's iterations in iteration order, `best_result` starting at None,
+ *   if best_result.map_or(true, |best| evaluate_action_impact(&to_ar(&result.metrics), &to_ar(&best.metrics), mode) > 0.0) { best_result = Some(result) }
+ * (arguments as written).  Continues a fold: *has / best[4] / *best_index come in as an earlier call left them (0 / - / -
+ * at the start); episodes with status != 0 are skipped.  Returns the number of take-overs in this call. */
+int32_t og_fold_best_result(int32_t n, const int32_t *status, const double *metrics /* [n][4] */, int32_t cost_only,
+                            int64_t first_index, int32_t *has, double best[4], int64_t *best_index);
+
 /* ---- "tabled" mode: the same episode evaluated from policy-independent tables (per-year settlement-term table,
  * memoised opinion/cost terms, incrementally maintained aggregates).  The tables are INPUTS here — the tests pass in
  * the ones the product library builds (eg_host_tables_*), which is how they are validated against the literal mode

@@ -25,7 +25,7 @@ def test_constants_agree_with_header(built):
     for name, val in (("EG_YEARS", N.YEARS), ("EG_N_ACTIONS", N.N_ACTIONS), ("EG_N_DEFICIT", N.N_DEFICIT),
                       ("EG_N_COUNTS", N.N_COUNTS), ("EG_MAX_GENS", N.MAX_GENS), ("EG_MAX_OFFSETS", N.MAX_OFFSETS),
                       ("EG_RUN_CAP", N.RUN_CAP), ("EG_DEF_CAP", N.DEF_CAP), ("EG_ACT_CAP", N.ACT_CAP),
-                      ("EG_YEARLY_FIELDS", N.YEARLY_FIELDS)):
+                      ("EG_YEARLY_FIELDS", N.YEARLY_FIELDS), ("EG_ONCHIP_GENS", N.ONCHIP_GENS)):
         assert int(re.search(rf"#define {name} (\d+)", header).group(1)) == val
 
 

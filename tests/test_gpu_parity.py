@@ -333,21 +333,62 @@ def test_both_kernels_agree_on_random_policies(world):
             eng.close()
 
 
-def test_capacity_overflow_is_reported_not_hidden(world):
-    """Maximum sizes: a best strategy with 30 generator additions in every year, replayed (and double-recorded, SURVEY
-    Q15), runs past EG_MAX_GENS / EG_RUN_CAP.  Such an episode must end with EG_EP_OVERFLOW in both kernels, with
-    identical bytes, never with a silently truncated result; seeded episodes of the same batch are untouched."""
+def _engines_by_helper_mode(world, slots=None):
     engines = {}
     for mode in ("0", "all"):
         os.environ["EIRGRID_HELPER_WAVES"] = mode
+        if slots is not None:
+            os.environ["EIRGRID_HEAVY_SLOTS"] = slots
         try:
             engines[mode] = Engine(world, device=0)
         finally:
             del os.environ["EIRGRID_HELPER_WAVES"]
+            os.environ.pop("EIRGRID_HEAVY_SLOTS", None)
+    return engines
+
+
+def _policy_with_best_lists(rng, per_year, types, offsets_per_year=0, deficit_max=3):
+    """An ActionWeights whose best strategy adds `per_year` generators (of `types`) and `offsets_per_year` carbon offsets in
+    every year, in random order, plus a few deficit actions."""
+    pol = ActionWeights()
+    run = []
+    for _ in range(26):
+        year = [int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(per_year)]
+        year += [int(45 + rng.integers(0, 12)) for _ in range(offsets_per_year)]
+        rng.shuffle(year)
+        run.append([int(a) for a in year])
+    dfl = [[int(3 * rng.choice([8, 7, 12, 11])) for _ in range(int(rng.integers(0, deficit_max)))] for _ in range(26)]
+    nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
+    pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.array([a for l in run for a in l], np.uint8), nd,
+                      np.array([a for l in dfl for a in l], np.uint8))
+    return pol
+
+
+_ALL_FIELDS = ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved",
+               "run_log", "def_log", "act_log", "gen_cell", "gen_pack", "off_pack")
+
+
+def _used(res, name):
+    """A list field with everything behind each episode's used length zeroed (the records are not cleared between batches: what
+    lies behind a list is whatever an earlier batch of that engine left there)."""
+    a = getattr(res, name)
+    if a.ndim != 2 or name in ("metrics", "n_run", "n_def", "n_act"):
+        return a
+    length = {"run_log": res.n_run.sum(axis=1), "def_log": res.n_def.sum(axis=1), "act_log": res.n_act.sum(axis=1),
+              "gen_cell": res.n_gens, "gen_pack": res.n_gens, "off_pack": res.n_offsets}[name]
+    return np.where(np.arange(a.shape[1])[None, :] < length[:, None], a, 0).astype(a.dtype)
+
+
+def test_capacity_overflow_is_reported_not_hidden(world):
+    """Maximum sizes.  The record capacities are the oracle's (4096 entries per list, include/eirgrid_hip.h): a best strategy
+    with 80 generator additions in every year, replayed (and double-recorded), would record 4160 actions.  Such an
+    episode must end with EG_EP_OVERFLOW in both kernels AND in the oracle, with identical bytes between the kernels, never
+    with a silently truncated result; seeded episodes of the same batch are untouched."""
+    engines = _engines_by_helper_mode(world)
     try:
         pol = ActionWeights()
-        nr = np.full(26, 30, np.int32); nd = np.zeros(26, np.int32)
-        pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.full(26 * 30, 36, np.uint8), nd, np.zeros(0, np.uint8))   # 36 = BatteryStorage 100 %
+        nr = np.full(26, 80, np.int32); nd = np.zeros(26, np.int32)
+        pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.full(26 * 80, 36, np.uint8), nd, np.zeros(0, np.uint8))   # 36 = BatteryStorage 100 %
         n = 64
         mask = (np.arange(n) % 2 == 0).astype(np.uint8)
         a = engines["0"].rollout_batch(pol, 5, n, replay_mask=mask)
@@ -356,14 +397,57 @@ def test_capacity_overflow_is_reported_not_hidden(world):
         assert (a.status[mask == 0] == 0).all()
         for name in ("status", "metrics", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws"):
             assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), name
-        assert (a.n_gens <= 512).all() and (a.n_run.sum(axis=1) <= 2048).all()
+        assert (a.n_gens <= 4096).all() and (a.n_run.sum(axis=1) <= 4096).all()
         tb = _tabled(world)
+        st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 5, replay=True)
+        assert st == -1, "the oracle overflows on the same episode"
         for e in (1, 33, 63):      # the seeded episodes of the batch against the oracle
             st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 5 + e, replay=False)
             assert_episode_equal(a, e, ref, "beside overflowing episodes")
     finally:
         for eng in engines.values():
             eng.close()
+
+
+def test_long_replay_episodes_beyond_the_onchip_window_match_the_oracle(world):
+    """The reference's lists are Vecs (core/simulation.rs:146-162, :406-409; sampling.rs:93-101, :258-266) and a replay doubles
+    them: configs[3] as a free-running loop reaches a 965-action best list by its eighth update.  Replay episodes of
+    ~600, ~1000 and ~2000 generators (and ~700 carbon offsets): beyond the 512 entries the kernels keep in LDS the long-replay
+    variant goes on in the episode's own record (eg_rollout.hip ListTail).  Every output bit-identical to the tabled oracle, in
+    both helper modes, with a field pool for every episode, for three of them (the others take place_exact_long) and none."""
+    tb = _tabled(world)
+    rng = np.random.default_rng(2026)
+    policies = [_policy_with_best_lists(rng, 23, [0, 4, 12, 7, 5], offsets_per_year=2),          # ~600 generators, three radius classes
+                _policy_with_best_lists(rng, 12, [0, 1, 13], offsets_per_year=27),               # ~310 generators, ~700 offsets
+                _policy_with_best_lists(rng, 39, list(range(15)), offsets_per_year=1),           # ~1000 generators, every class
+                _policy_with_best_lists(rng, 76, [12, 2, 3, 8, 9, 4], offsets_per_year=0, deficit_max=2)]   # ~2000 generators, 3 km class
+    n = 24
+    mask = (np.arange(n) % 3 != 1).astype(np.uint8)
+    results = {}
+    for slots, which in ((None, range(4)), ("3", (0, 2)), ("0", (0,))):
+        engines = _engines_by_helper_mode(world, slots)
+        try:
+            for mode, eng in engines.items():
+                results[(mode, slots)] = {k: eng.rollout_batch(policies[k], 77 + k, n, first_episode_index=100 * k, replay_mask=mask) for k in which}
+        finally:
+            for eng in engines.values():
+                eng.close()
+    ref_runs = results[("0", None)]
+    sizes = []
+    for k, pol in enumerate(policies):
+        a = ref_runs[k]
+        assert (a.status == 0).all(), (k, a.status.tolist())
+        sizes.append((int(a.n_gens[mask == 1].min()), int(a.n_gens.max()), int(a.n_offsets.max()), int(a.n_run.sum(axis=1).max())))
+        for key, runs in results.items():
+            if k not in runs:
+                continue
+            for name in _ALL_FIELDS:
+                assert _used(a, name).tobytes() == _used(runs[k], name).tobytes(), (k, key, name)
+        for e in (0, 1, 2, 9, 23):
+            st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 77 + k + 100 * k + e, replay=bool(mask[e]))
+            assert_episode_equal(a, e, ref, f"policy {k}, {'replay' if mask[e] else 'sampled'}")
+    print("generators (min replay, max) / offsets / recorded actions per policy:", sizes)
+    assert sizes[0][0] > 550 and sizes[1][2] > 650 and sizes[2][0] > 950 and sizes[3][0] > 1900 and sizes[3][3] > 3900
 
 
 @pytest.mark.parametrize("variant", [1, 2])
