@@ -18,18 +18,22 @@ so that the K timed steps last at least --min-seconds (0.5 s) — `steps`, `warm
 Reference semantics kept: a replay episode records and applies every action twice, so once a replay
 episode becomes the best strategy the replayed lists — and the generators each replay episode places — double.  Left to
 itself the loop therefore changes its own workload, and differently for every global batch size: from the seeded policy
-a replay episode places 228 generators at N = 1 for as long as the bench runs, while 4 x 16 384 episodes per update reach
-an 821-action best list within the warm-up (every replay then ends in EG_EP_OVERFLOW at 512 generators).  A benchmark
-needs the same work per GPU at every N, so by default every batch starts from the SAME policy — the seeded one, put back
-on the device before each batch by eg_policy_rewind (a device-to-device copy inside the timed region); the batch's update
-runs in full.  `--trajectory` lets the policy evolve instead (DESIGN.md §4 has those numbers).  The line reports what the
+(config 1's episode as the best strategy: 35 generators per replay episode) the single-GPU loop reaches a 257-action best
+list — 228 generators per replay episode — after five wins and stays there; larger global batches go further (965 actions
+at 131 072 episodes per update, profiles/r03a_replay_study_131072_fresh.json).
+HEADLINE (since round 3) = the state the loop SUSTAINS, not the one it starts in: every batch starts from the policy the
+single-GPU training loop holds GROW_BATCHES batches after the seeded one (every rank grows it alike, without exchange), put
+back on the device before each batch by eg_policy_rewind (a device-to-device copy inside the timed region) so that the work
+per GPU is the same at every N; the batch's update runs in full.  The seeded state — what rounds 1-2 reported as `value`:
+2.5x faster, and gone after about five updates of a real run — is the line's `config2_seeded` object (`--seeded` makes it the
+headline).  `--trajectory` lets the policy evolve instead (DESIGN.md §4 has those numbers).  The line reports what the
 batches did: `config.replay` (generators per replay / seeded episode, best-list length), `config.policy` and
 `config.episodes_failed` (EG_EP_OVERFLOW etc.; failed episodes are NOT counted in `value`).
 
-The N = 1 line also carries `config2_grown` (the same batches from the grown-replay state: the policy the single-GPU loop
-holds 48 batches after the seeded one, where a replay episode places 228 generators — what rounds 1-2 optimised and what
-`--grown` measures as the headline), `config1` (BASELINE configs[1]: 1 024 episodes per batch, no replay), each with a timed
-region and a `roofline` of its own, and `cpu_baseline`.
+The N = 1 line also carries `config1` (BASELINE configs[1]: 1 024 episodes per batch, no replay), with a timed region and a
+`roofline` of its own like `config2_seeded`, and `cpu_baseline`.  `roofline.traffic / hbm_frac_measured / valu_busy` come from
+the committed counter profiles of the same command and are quoted only when that profile was taken on the very library
+being timed (eg_build_hash); `frac_requested` bills only what the code requests from memory.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
@@ -67,16 +71,30 @@ def host_cores() -> int:
 
 
 def newest_profile(pattern: str, key: str, sub: str):
-    """(value, file name) of the newest committed profiles/<pattern> that has an entry for `sub` under `key`."""
+    """(value, file name, build hash) of the newest committed profiles/<pattern> that has an entry for `sub` under `key`."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
-            cfg = json.load(open(path))[key].get(sub)
+            doc = json.load(open(path))
+            cfg = doc[key].get(sub)
         except (OSError, ValueError, KeyError, AttributeError):
             continue
         if cfg:
-            best = (cfg, os.path.basename(path))
+            best = (cfg, os.path.basename(path), doc.get("build_hash"))
     return best
+
+
+def library_hash() -> str:
+    from eirgrid_amd import _native as N
+    return N.lib().eg_build_hash().decode()
+
+
+def stale(name: str, profile_hash) -> dict:
+    """Counters cannot be collected from inside the process: they come from a committed profile of the same command.  A profile
+    that was taken on another build of the library says nothing about the binary being timed: it is named, not quoted."""
+    return {"stale": True, "profile": name,
+            "reason": f"profiles/{name} was taken on build {profile_hash or 'unknown (no build_hash recorded)'}, the library being timed is "
+                      f"{library_hash()}: counters not quoted (scripts/refresh_profiles.sh regenerates them)"}
 
 
 def pmc_traffic(workload: str):
@@ -87,7 +105,9 @@ def pmc_traffic(workload: str):
     hit = newest_profile("*pmc_hbm_traffic.json", "configs", workload)
     if not hit:
         return None
-    cfg, name = hit
+    cfg, name, built = hit
+    if built != library_hash():
+        return stale(name, built)
     if "kernel_ns" in cfg:
         dur = cfg["kernel_ns"] * 1e-9
     else:      # (profiles of round 1: one grid per launch)
@@ -102,7 +122,9 @@ def sq_counters(workload: str):
     hit = newest_profile("*sq_counters.json", "runs", workload)
     if not hit:
         return None
-    run, name = hit
+    run, name, built = hit
+    if built != library_hash():
+        return stale(name, built)
     try:
         clock_hz = float(run.get("clock_hz", 2.4e9))
         busy = run["SQ_ACTIVE_INST_VALU"] * 4.0 / (CUS * SIMDS_PER_CU * run["duration_ns"] * 1e-9 * clock_hz)
@@ -179,7 +201,8 @@ def batch_census(eng, episodes, first, period, had_best):
             "replay_episodes": int(rep.sum()),
             "generators_per_seeded_episode": mean(res.n_gens[ok & ~rep]), "generators_per_replay_episode": mean(res.n_gens[ok & rep]),
             "chunks_per_search": float(res.n_chunks[ok].sum()) / max(float(res.n_gens[ok].sum()), 1.0),
-            "nominal_bytes": float(res.bytes_moved[ok].sum()), "touched_bytes": float(res.bytes_touched()[ok].sum())}
+            "nominal_bytes": float(res.bytes_moved[ok].sum()), "touched_bytes": float(res.bytes_touched()[ok].sum()),
+            "requested_bytes": float(res.bytes_requested()[ok].sum())}
 
 
 def timed_loop(trainer, eng, fence, batches):
@@ -199,25 +222,37 @@ def roofline_object(workload, census, episodes, avg_kernel_s):
     """`achieved` = bytes the implemented algorithm touches per launch / measured kernel time (the SURVEY formula with the
     2601 x 8 B score field of every search replaced by the candidate records the branch-and-bound search requested);
     `nominal_*` = the SURVEY §8(d) formula as written (it bills the field, which this kernel never reads);
-    `traffic` = HBM bytes per launch from the committed PMC profile of this workload; `hbm_frac_measured` = that traffic
+    `frac_requested` = only what the code requests from the memory system (BatchResult.bytes_requested: no state term — that
+    state lives in LDS — and no generator coordinates) over the same time;
+    `traffic` = HBM bytes per launch from the committed PMC profile of this workload — quoted only when that profile was
+    taken on the very build being timed (eg_build_hash), null with the reason otherwise; `hbm_frac_measured` = that traffic
     over the kernel time of the same profiled launches over peak; `valu_busy` from the committed SQ counters.  `bound`
     says what the counters say: the kernel is bound by VALU issue / latency of its serial episode waves, not by HBM."""
     touched = census["touched_bytes"] * episodes / max(census["ok"], 1)
     nominal = census["nominal_bytes"] * episodes / max(census["ok"], 1)
+    requested = census["requested_bytes"] * episodes / max(census["ok"], 1)
     achieved = touched / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     tr, sq = pmc_traffic(workload), sq_counters(workload)
+    notes = [x["reason"] for x in (tr, sq) if x and x.get("stale")]
+    tr_ok = tr if tr and not tr.get("stale") else None
+    sq_ok = sq if sq and not sq.get("stale") else None
     obj = {"bound": "valu-issue/latency (HBM roofline not the limiter: see hbm_frac_measured, valu_busy)",
+           "hbm_frac_measured": (tr_ok["bytes"] / tr_ok["kernel_s"] / 1e9 / HBM_PEAK_GBS) if tr_ok and tr_ok["kernel_s"] else None,
            "achieved": achieved, "peak": HBM_PEAK_GBS, "peak_measured": measured_peak(), "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
-           "hbm_frac_measured": (tr["bytes"] / tr["kernel_s"] / 1e9 / HBM_PEAK_GBS) if tr and tr["kernel_s"] else None,
-           "valu_busy": sq["valu_busy"] if sq else None,
-           "valu_busy_grids": {k[10:-5]: v for k, v in sq.items() if k.startswith("valu_busy_") and k.endswith("_grid")} if sq else None,
+           "frac": achieved / HBM_PEAK_GBS,
+           "frac_requested": requested / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else 0.0,
+           "traffic": tr_ok["bytes"] if tr_ok else None,
+           "valu_busy": sq_ok["valu_busy"] if sq_ok else None,
+           "valu_busy_grids": {k[10:-5]: v for k, v in sq_ok.items() if k.startswith("valu_busy_") and k.endswith("_grid")} if sq_ok else None,
            "kernel": "k_rollout", "avg_kernel_ms": avg_kernel_s * 1e3,
            "touched_bytes_per_launch": touched, "touched_bytes_per_episode": touched / max(episodes, 1),
+           "requested_bytes_per_launch": requested, "requested_bytes_per_episode": requested / max(episodes, 1),
            "nominal_bytes_per_launch": nominal, "nominal_frac": nominal / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else 0.0,
            "chunks_per_search": census["chunks_per_search"],
            "kernel_only_episodes_per_s": episodes / avg_kernel_s if avg_kernel_s > 0 else 0.0,
-           "profiles": {"traffic": tr["profile"] if tr else None, "sq": sq["profile"] if sq else None}}
+           "profiles": {"traffic": tr["profile"] if tr else None, "sq": sq["profile"] if sq else None, "library": library_hash()}}
+    if notes:
+        obj["counters_not_quoted"] = notes
     return obj
 
 
@@ -242,15 +277,20 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="rehearsal: initialise torch.distributed and issue the per-update collectives even with one rank")
-    ap.add_argument("--grown", action="store_true",
-                    help="measure the grown-replay state instead of the seeded one: the policy the single-GPU training loop holds after "
-                         f"{GROW_BATCHES} batches from the seeded policy (best list 257 actions, a replay episode places 228 generators); the N = 1 "
-                         "line carries that measurement as its `config2_grown` object anyway")
+    ap.add_argument("--seeded", action="store_true",
+                    help="headline = the seeded policy (SURVEY §8(d) config 3 read literally: a fresh policy whose best strategy is config 1's "
+                         "episode, 35 generators per replay episode) instead of the state the training loop sustains; the N = 1 line carries "
+                         "that measurement as its `config2_seeded` object anyway")
+    ap.add_argument("--grown", action="store_true", help="(the default since round 3; kept for the scripts that pass it)")
     ap.add_argument("--trajectory", action="store_true",
                     help="let the policy evolve from batch to batch (the training loop as it runs) instead of starting every batch "
                          "from the seeded policy; what a replay episode costs then depends on the run and on N (SURVEY Q15)")
     ap.add_argument("--no-yearly", action="store_true", help="skip the 26x21 yearly rows (the reference always produces them)")
     args = ap.parse_args()
+    # The headline is the SUSTAINED state of configs[2]: the policy the single-GPU training loop holds GROW_BATCHES batches after the
+    # seeded one (its replayed list has stopped growing: 257 actions, 228 generators per replay episode).  The seeded policy itself
+    # — 35 generators per replay episode — lasts about five updates of a real run; it is reported beside it (config2_seeded).
+    args.grown = not args.seeded
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # convenience: relaunch under torchrun as a child process
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -403,19 +443,23 @@ def main():
             "roofline": roofline_object(wkey, census, args.episodes, m["avg_kernel_s"]),
         }
     # ---- second object (N = 1): the grown-replay state of the same workload — what the training loop turns configs[2] into ----
-    if world_size == 1 and not args.no_config1 and args.replay_fraction > 0.0 and not args.grown and not args.trajectory:
-        wg = seeded_policy(True)
+    if world_size == 1 and not args.no_config1 and args.replay_fraction > 0.0 and not args.trajectory:
+        other_grown = not args.grown      # the state the headline was NOT measured in
+        wg = seeded_policy(other_grown)
         tg = BatchTrainer(eng, wg, args.episodes, args.seed, 0, 1, None, replay_fraction=args.replay_fraction,
                           write_yearly=not args.no_yearly, device_resident=True)
         tg.pin_policy()
         g = measure(tg, wg)
-        line["config2_grown"] = {"workload": f"the same batches from the grown-replay state: {policy_text(True)}",
+        line["config2_grown" if other_grown else "config2_seeded"] = {
+                                 "workload": ("the same batches from the grown-replay state: " if other_grown else
+                                              "the same batches from the seeded policy, as SURVEY §8(d) words config 3 (a state the free-running loop "
+                                              "leaves within about five updates): ") + policy_text(other_grown),
                                  "value": g["value"], "unit": "episodes/s", "batches_timed": g["batches"], "timed_region_s": g["elapsed"],
                                  "ms_per_batch": g["elapsed"] / g["batches"] * 1e3, "episodes_failed": g["failed"],
                                  "last_batch": {k: g["census"][k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
                                                                             "generators_per_seeded_episode", "generators_per_replay_episode")},
                                  "replay": g["replay"],
-                                 "roofline": roofline_object(workload_key(args.episodes, args.replay_fraction) + "grown", g["census"],
+                                 "roofline": roofline_object(workload_key(args.episodes, args.replay_fraction) + ("grown" if other_grown else ""), g["census"],
                                                              args.episodes, g["avg_kernel_s"])}
     # ---- second object: BASELINE configs[1] (1024 episodes per batch, no replay), its own policy and timed region ----
     if world_size == 1 and not args.no_config1 and not (args.episodes == 1024 and args.replay_fraction == 0.0):

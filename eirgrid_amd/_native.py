@@ -93,8 +93,8 @@ def lib():
         raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  eirgrid_amd has no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    L.eg_build_hash.restype = C.c_char_p
     if not os.environ.get("EIRGRID_LIB"):      # a stale or mixed binary (e.g. a prebuilt .so shipped next to edited sources) fails loudly
-        L.eg_build_hash.restype = C.c_char_p
         built, tree = L.eg_build_hash().decode(), source_hash()
         if built != tree:
             raise ImportError(f"{LIB_PATH} was built from other sources (library {built}, tree {tree}): run `make -C eirgrid_amd/csrc`")

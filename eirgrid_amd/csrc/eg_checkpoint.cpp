@@ -280,7 +280,7 @@ int32_t eg_policy_export_improvement_csv(const eg_policy* p, const char* path) {
 
 // simulation_summary.csv of the best-run export (utils/csv_export.rs:215-432): final metrics, one row per action of
 // SimulationResult.actions with the exporter's cost estimate, one row per year of YearlyMetrics.  `run` holds ONE episode
-// (the record eg_fetch_best_run / eg_fetch_record return; metrics, yearly, n_act and act_log are read).
+// (the record eg_fetch_best_result / eg_fetch_record return; metrics, yearly, n_act and act_log are read).
 int32_t eg_export_summary_csv(const eg_episode_out* run, const char* path, const char* timestamp) {
   if (!run || !path || !run->metrics || !run->yearly || !run->n_act || !run->act_log) {
     eg::set_error("eg_export_summary_csv: metrics, yearly, n_act and act_log are required"); return EG_ERR_BAD_ARG;

@@ -43,6 +43,7 @@ struct Args {   // cli/cli.rs:5-59
   std::string world_json, assets_dir = "aiSimulator/assets"; uint32_t batch = 1024; std::string update = "reduced"; int device = 0;
   bool existing_operational_at_start = false;
   uint64_t stop_after = 0;      // leave the loop (as an interrupt would) once this many iterations are done and checkpointed
+  std::string dump_world;       // write the loaded world (eirgrid_amd JSON form) there and exit: no device needed
 };
 
 void usage() {
@@ -57,7 +58,8 @@ void usage() {
             "      --assets-dir <DIR>   settlements.json, ireland_generators.csv, coastline_points.json [default: aiSimulator/assets]\n"
             "      --batch <B>          iterations per GPU launch [default: 1024]\n      --update <sequential|reduced>  [default: reduced]\n"
             "      --device <N>         [default: 0]\n      --existing-operational-at-start\n"
-            "      --stop-after <N>     stop like an interrupted run once N iterations are done and checkpointed (resume tests)");
+            "      --stop-after <N>     stop like an interrupted run once N iterations are done and checkpointed (resume tests)\n"
+            "      --dump-world <FILE>  write the world as loaded (the --world JSON form) and exit; needs no GPU");
 }
 
 bool parse(int argc, char** argv, Args& a) {
@@ -93,6 +95,7 @@ bool parse(int argc, char** argv, Args& a) {
     else if (s == "--device") a.device = std::atoi(v().c_str());
     else if (s == "--existing-operational-at-start") a.existing_operational_at_start = true;
     else if (s == "--stop-after") a.stop_after = std::strtoull(v().c_str(), nullptr, 10);
+    else if (s == "--dump-world") a.dump_world = v();
     else if (s == "-h" || s == "--help") { usage(); std::exit(0); }
     else { std::fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage(); return false; }
   }
@@ -207,6 +210,32 @@ int main(int argc, char** argv) {
   if (!a.world_json.empty()) { if (!load_world_json(a.world_json, wd)) { std::fprintf(stderr, "error: cannot read world %s\n", a.world_json.c_str()); return 1; } }
   else if (!load_reference_assets(a.assets_dir, wd)) { std::fprintf(stderr, "error: cannot read %s/{settlements.json,ireland_generators.csv} (use --world or --assets-dir)\n", a.assets_dir.c_str()); return 1; }
   std::printf("World: %zu settlements, %zu existing generators, %zu coastline points\n", wd.sx.size(), wd.gx.size(), wd.cx.size());
+  {  // the fuel mix as data/generators_loader.rs:47-57 maps it (gas -> GasCombinedCycle, oil -> GasPeaker, ...)
+    static const char* kTypeName[EG_N_TYPES] = {"OnshoreWind", "OffshoreWind", "DomesticSolar", "CommercialSolar", "UtilitySolar", "Nuclear", "CoalPlant",
+                                                "GasCombinedCycle", "GasPeaker", "Biomass", "HydroDam", "PumpedStorage", "BatteryStorage", "TidalGenerator", "WaveEnergy"};
+    int count[EG_N_TYPES] = {0};
+    for (int32_t t : wd.gtype) if (t >= 0 && t < EG_N_TYPES) count[t] += 1;
+    std::string mix;
+    for (int t = 0; t < EG_N_TYPES; ++t) if (count[t]) mix += (mix.empty() ? "" : ", ") + std::string(kTypeName[t]) + " " + std::to_string(count[t]);
+    std::printf("Existing generators by type: %s\n", mix.c_str());
+  }
+  if (!a.dump_world.empty()) {
+    std::ofstream f(a.dump_world);
+    if (!f) { std::fprintf(stderr, "error: cannot write %s\n", a.dump_world.c_str()); return 1; }
+    auto arr = [&](const char* key, const std::vector<double>& v, bool last = false) {
+      f << "\"" << key << "\": [";
+      char buf[40];
+      for (size_t i = 0; i < v.size(); ++i) { std::snprintf(buf, sizeof(buf), "%.17g", v[i]); f << (i ? ", " : "") << buf; }
+      f << "]" << (last ? "" : ", ");
+    };
+    f << "{";
+    arr("settlement_x", wd.sx); arr("settlement_y", wd.sy); arr("settlement_pop", std::vector<double>(wd.spop.begin(), wd.spop.end()));
+    arr("existing_x", wd.gx); arr("existing_y", wd.gy); arr("existing_type", std::vector<double>(wd.gtype.begin(), wd.gtype.end()));
+    arr("existing_capacity", wd.gcap); arr("coast_x", wd.cx); arr("coast_y", wd.cy);
+    f << "\"existing_operational_at_start\": " << (a.existing_operational_at_start ? "true" : "false") << "}\n";
+    std::printf("World written to %s\n", a.dump_world.c_str());
+    return 0;
+  }
   const eg_world world = wd.view(a.existing_operational_at_start);
   eg_ctx* ctx = eg_create(a.device, &world);
   if (!ctx) { std::fprintf(stderr, "eg_create: %s\n", eg_last_error()); return 1; }

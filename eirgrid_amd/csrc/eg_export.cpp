@@ -3,7 +3,7 @@
 //   <dir>/yearly_details/generators.csv        utils/csv_export.rs:535-985
 //   <dir>/yearly_details/carbon_offsets.csv    utils/csv_export.rs:987-1092
 //   <dir>/operation_logs/generator_operation_logs.csv   utils/csv_export.rs:1094-1230
-// written from the record of the best episode (eg_fetch_best_run / eg_fetch_record) and the world description.
+// written from the record of the best episode (eg_fetch_best_result / eg_fetch_record) and the world description.
 //
 // What the reference's exporter really emits (core/multi_simulation.rs:852-905 builds a "final map" = the base map with the
 // best episode's SAMPLED actions re-applied, and hands it over with the episode's YearlyMetrics):

@@ -2442,7 +2442,7 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     double* best_w = reinterpret_cast<double*>(snap_base + snap::best_w);
     for (int i = tid; i < Y * NA; i += 1024) { const int y = i / NA, a = i - y * NA; best_w[i] = pol[y * snap::kPolRow + a]; }
     // the whole record of the winning episode (yearly rows, action list, placements) stays with the policy when the
-    // episode ran here: what the reference keeps as `best_result` for its export (multi_simulation.rs:494-508, :852-905)
+    // episode ran here (eg_fetch_best_run; the run the reference exports is another one, see k_fold_best)
     if (s_owned) {
       const unsigned long long* src = reinterpret_cast<const unsigned long long*>(out_base + (size_t)(c->index - (long long)first_index) * rec::stride);
       unsigned long long* dst = reinterpret_cast<unsigned long long*>(snap_base + snap::best_rec);

@@ -236,6 +236,29 @@ class BatchResult:
         branch-and-bound search) replaced by the candidate records the search requested (n_chunks x 64 x 32 B)."""
         return self.bytes_moved - self.n_gens.astype(np.float64) * (N.CELLS * 8.0) + self.n_chunks.astype(np.float64) * (64 * 32.0)
 
+    def bytes_requested(self) -> np.ndarray:
+        """Per episode: the bytes the kernel REQUESTS from the memory system (L2 or HBM), by construction of the code — without
+        the SURVEY formula's state term `2 (59 + G) 56` per year (state that lives in LDS: 3 bytes per generator) and without the
+        generator coordinates a search reads (LDS as well):
+          n_chunks x 2048                       sorted candidate records in chunks of 64 x 32 B; long-replay episodes: + the entries of
+                                                their penalty field they gather and update (counted by the kernel)
+          32 x sum_g (25 - b_g)                 year-start gathers per generator and later year: {cost, cost opinion} 16 B, m03 8 B, t12 8 B
+          16 x sum_o (25 - b_o)                 per carbon offset and later year: tonnes 8 B, cost 8 B
+          32 x n_gens + 24 x n_offsets          the terms of an addition itself
+          26 x 1024                             the policy row block of every year (128 doubles)
+          26 x 168 + 3 x 104 + 72               stores: yearly rows, per-year counts, record header
+          2 x (run + def) + act + 4 x n_gens + 2 x n_offsets    stores: logs (run and def re-read by the statistics epilogue), placements"""
+        n = len(self.status)
+        out = np.zeros(n)
+        for e in range(n):
+            g, o = int(self.n_gens[e]), int(self.n_offsets[e])
+            by = (self.gen_pack[e, :g].astype(np.int64) >> 4) & 31
+            oy = (self.off_pack[e, :o].astype(np.int64) >> 4) & 31
+            logs = 2.0 * (self.n_run[e].sum() + self.n_def[e].sum()) + self.n_act[e].sum()
+            out[e] = (self.n_chunks[e] * 2048.0 + 32.0 * (25 - by).sum() + 16.0 * (25 - oy).sum() + 32.0 * g + 24.0 * o + 26 * 1024.0
+                      + 26 * 168.0 + 3 * 104.0 + 72.0 + logs + 4.0 * g + 2.0 * o)
+        return out
+
     def lists(self, e: int, which: str):
         log = {"run": self.run_log, "def": self.def_log, "act": self.act_log}[which][e]
         cnt = {"run": self.n_run, "def": self.n_def, "act": self.n_act}[which][e]
@@ -393,8 +416,9 @@ class Engine:
         return res
 
     def fetch_best_run(self):
-        """(state, record): the record of the best episode kept by the on-device update (multi_simulation.rs:494-508 keeps
-        the best SimulationResult).  state 0 = no improvement yet, 1 = record valid, 2 = it ran on another rank."""
+        """(state, record): the record of the episode that is the policy's best strategy (strategy.rs:19-258), kept by the
+        on-device update.  state 0 = no improvement yet, 1 = record valid, 2 = it ran on another rank.  (The run the reference
+        exports is another one: fetch_best_result.)"""
         res = BatchResult.alloc(1)
         out = res.struct()
         state = C.c_int32(0)

@@ -45,7 +45,10 @@ def avg(rs, key):
 
 def main():
     tag, out_dir, specs = sys.argv[1], sys.argv[2], sys.argv[3:]
-    doc = {"note": __doc__.strip().split("\n\n", 1)[1], "configs": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from eirgrid_amd import _native as N
+    # the library the counters were taken on: bench.py only quotes a profile whose hash is the loaded library's
+    doc = {"note": __doc__.strip().split("\n\n", 1)[1], "build_hash": N.lib().eg_build_hash().decode(), "configs": {}}
     for spec in specs:
         wl, fd, wd = spec.split(":")
         f, w = rows(fd, "FETCH_SIZE"), rows(wd, "WRITE_SIZE")

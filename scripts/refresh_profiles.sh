@@ -1,15 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): regenerates everything under profiles/ for tag $1 into gpurun_out/<tag>_*.
 #   bash scripts/refresh_profiles.sh r02a      then copy gpurun_out/r02a_* into profiles/
-# Workloads: "16384r0.1" = BASELINE configs[2] (bench.py default: every batch from the seeded policy), "16384r0.1grown" = the same
-# batches from the grown-replay state (--grown: 228 generators per replay episode), "1024" = configs[1] (--episodes 1024 --replay-fraction 0).
+# Workloads: "16384r0.1grown" = BASELINE configs[2] in the state the training loop sustains (bench.py default: 228 generators per
+# replay episode), "16384r0.1" = the same batches from the seeded policy (--seeded), "1024" = configs[1] (--episodes 1024 --replay-fraction 0).
 set -eo pipefail
 tag=${1:-r02a}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-C2="--steps 20 --warmup 5 --no-cpu-baseline --no-config1"
-CG="$C2 --grown"
+CG="--steps 20 --warmup 5 --no-cpu-baseline --no-config1"
+C2="$CG --seeded"
 C1="--steps 20 --warmup 5 --no-cpu-baseline --episodes 1024 --replay-fraction 0 --batches-per-step 8"
 python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 echo "bench done"
@@ -21,8 +21,8 @@ cp $(ls $O/prof_${tag}_cg/*/*kernel_stats.csv | head -1) $O/${tag}_bench_c2grown
 cp $(ls $O/prof_${tag}_c1/*/*kernel_stats.csv | head -1) $O/${tag}_bench_c1_kernel_stats.csv
 echo "kernel stats done"
 # counters: separate passes, nothing but --pmc (MI355X_MICROARCH.md, HBM / rocprofv3 section)
-P2="--steps 4 --warmup 2 --no-cpu-baseline --no-config1 --batches-per-step 2"
-PG="$P2 --grown"
+PG="--steps 4 --warmup 2 --no-cpu-baseline --no-config1 --batches-per-step 2"
+P2="$PG --seeded"
 P1="--steps 4 --warmup 2 --no-cpu-baseline --episodes 1024 --replay-fraction 0 --batches-per-step 2"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_${tag}_f_c2 --output-format csv -- python3 bench.py $P2 > $O/pmc_${tag}.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_${tag}_w_c2 --output-format csv -- python3 bench.py $P2 >> $O/pmc_${tag}.log 2>&1

@@ -12,6 +12,9 @@ doc = {"note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST
                "(1024 SIMDs * duration * 2.4 GHz), duration = the grids one after the other (counter collection serialises dispatches; "
                "the un-profiled launch overlaps them). 1024 episodes per launch run k_rollout<1,.> (episode wave + helper wave), 16384 k_rollout<0,.>.",
        "runs": {}}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eirgrid_amd import _native as N
+doc["build_hash"] = N.lib().eg_build_hash().decode()      # the library the counters were taken on (bench.py checks it)
 for spec in specs:
     wl, d = spec.split(":")
     per = {"heavy": {}, "short": {}, "lean": {}}
