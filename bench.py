@@ -214,7 +214,8 @@ def timed_loop(trainer, eng, fence, batches):
         trainer.step()
     fence()
     elapsed = time.perf_counter() - t0
-    ms, n = eng.timing_read()
+    ms, grids_ms, n = eng.timing_read_grids()
+    timed_loop.grids_ms = grids_ms      # (the grids' own durations added up: side-by-side grids show span < sum)
     return elapsed, ms, n
 
 
@@ -390,7 +391,7 @@ def main():
         tr.sync()                     # device-resident policy -> host copy (after the timed region)
         batches = args.steps * bps
         return {"bps": bps, "calibration": calibration, "elapsed": elapsed, "batches": batches, "failed": failed, "census": census,
-                "avg_kernel_s": kernel_ms / max(n_launch, 1) * 1e-3, "value": (args.episodes * tr.ws * batches - failed) / elapsed,
+                "avg_kernel_s": kernel_ms / max(n_launch, 1) * 1e-3, "avg_grids_s": timed_loop.grids_ms / max(n_launch, 1) * 1e-3, "value": (args.episodes * tr.ws * batches - failed) / elapsed,
                 "replay": replay}
 
     def policy_text(grown: bool) -> str:
@@ -442,6 +443,9 @@ def main():
                            "iterations_without_improvement": int(weights.get("iterations_without_improvement"))} if args.trajectory else {})},
             "roofline": roofline_object(wkey, census, args.episodes, m["avg_kernel_s"]),
         }
+        # the grids of a batch (replay variants on the side stream, the rest on the null stream), from the library's own events
+        line["roofline"]["grids"] = {"span_ms": m["avg_kernel_s"] * 1e3, "sum_of_grids_ms": m["avg_grids_s"] * 1e3,
+                                     "overlap": 1.0 - m["avg_kernel_s"] / m["avg_grids_s"] if m["avg_grids_s"] > 0 else 0.0}
     # ---- second object (N = 1): the grown-replay state of the same workload — what the training loop turns configs[2] into ----
     if world_size == 1 and not args.no_config1 and args.replay_fraction > 0.0 and not args.trajectory:
         other_grown = not args.grown      # the state the headline was NOT measured in

@@ -82,6 +82,7 @@ struct eg_ctx {
   uint32_t* d_index = nullptr; uint32_t index_cap = 0;         // replay / other episode indices of a host-masked batch
   int ring_head = 0, ring_pending = 0;      // next pair to use; pairs recorded and not yet collected (the oldest is head - pending)
   double total_ms = 0.0; int32_t n_launches = 0;
+  double grids_ms = 0.0;      // the same launches, every grid's own duration added up (== total_ms when a batch is one grid)
   // eg_place / eg_find_suitable_location: device buffers kept between calls
   uint16_t* d_place_cells = nullptr; int32_t* d_place_cell = nullptr; double* d_place_score = nullptr;
   double* d_place_xy = nullptr; int32_t place_xy_cap = 0;
@@ -128,7 +129,14 @@ int collect_timing(eg_ctx* c, int count = -1) {
   for (; count > 0; --count) {
     const int i = (c->ring_head - c->ring_pending + 2 * eg_ctx::kTimingRing) % eg_ctx::kTimingRing;
     const bool heavy = c->ev_used[i] & 1, lean = c->ev_used[i] & 2;
-    float best = 0.f;
+    float best = 0.f, sum = 0.f;
+    for (int g = 0; g < 2; ++g)
+      if (g ? lean : heavy) {
+        EG_HIP(hipEventSynchronize(c->ev[i][2 * g + 1]));
+        float ms = 0.f;
+        EG_HIP(hipEventElapsedTime(&ms, c->ev[i][2 * g], c->ev[i][2 * g + 1]));
+        sum += ms;
+      }
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
         if (!(a ? lean : heavy) || !(b ? lean : heavy)) continue;
@@ -137,7 +145,7 @@ int collect_timing(eg_ctx* c, int count = -1) {
         EG_HIP(hipEventElapsedTime(&ms, c->ev[i][2 * a], c->ev[i][2 * b + 1]));
         if (ms > best) best = ms;
       }
-    c->total_ms += double(best); c->n_launches += 1; c->ring_pending -= 1;
+    c->total_ms += double(best); c->grids_ms += double(sum); c->n_launches += 1; c->ring_pending -= 1;
   }
   return EG_OK;
 }
@@ -816,7 +824,15 @@ int32_t eg_rollout_batch(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts* 
 int32_t eg_timing_reset(eg_ctx* c) {
   if (!c) return EG_ERR_BAD_ARG;
   int rc = collect_timing(c);
-  c->total_ms = 0.0; c->n_launches = 0;
+  c->total_ms = 0.0; c->grids_ms = 0.0; c->n_launches = 0;
+  return rc;
+}
+int32_t eg_timing_read_grids(eg_ctx* c, double* span_ms, double* grids_ms, int32_t* n_launches) {
+  if (!c) return EG_ERR_BAD_ARG;
+  int rc = collect_timing(c);
+  if (span_ms) *span_ms = c->total_ms;
+  if (grids_ms) *grids_ms = c->grids_ms;
+  if (n_launches) *n_launches = c->n_launches;
   return rc;
 }
 int32_t eg_timing_read(eg_ctx* c, double* total_ms, int32_t* n_launches) {

@@ -132,6 +132,11 @@ struct DevState {
   double best_metrics[4];
   double rel_improvement, immediate_weight;                   // learning.rs:37-55
   double p_best_score, p_threshold, p_adaptive_lr, p_stagnation;   // contrast step, learning.rs:131-180
+  // expressions of the scalars that every action or nudge of an episode evaluates (derive_state): 1 + lr * 0.1 and 1 + lr * 0.2
+  // (learning.rs:74-87, deficit.rs:118-127), the stall-scaled exploration rate of sample_action (sampling.rs:150-157), the power
+  // of the stalled sampler 1 + 2 min(stall / 1000, 3) (sampling.rs:193-195).  As loads they become scalar registers of the
+  // episode; as loop-invariant f64 expressions the compiler hoisted them into vector registers and spilled them.
+  double boost_others, boost_noop, eps_main, scaled_power;
   uint32_t stall, iteration_count;
   int32_t has_best, has_cw, noop_boost, has_lists, p_forced;
   uint32_t heur_min, heur_max;                                // sampling.rs:425-427
@@ -192,6 +197,11 @@ struct DevSnapshot {
   double immediate_weight;     // learning.rs:54
   int32_t has_best_actions, has_best_deficit;
   uint32_t heur_min, heur_max;   // sampling.rs:425-427 (count table absent)
+  // expressions of the scalars above that every action or nudge evaluates (kept as scalars: a loop-invariant f64 expression
+  // of uniform values is hoisted by the compiler into VECTOR registers and held there for the whole episode)
+  double boost_others, boost_noop;   // 1 + lr * 0.1, 1 + lr * 0.2 (learning.rs:74-87, deficit.rs:118-127)
+  double eps_main;                   // exploration rate of sample_action, stall-scaled (sampling.rs:150-157)
+  double scaled_power;               // 1 + 2 * min(stall / 1000, 3) (sampling.rs:193-195)
 #define EG_SNAP(name, type) EG_HD const type* name() const { return reinterpret_cast<const type*>(base + snap::name); }
   EG_SNAP(pol, double) EG_SNAP(scaled, double) EG_SNAP(scaled_perm, uint8_t)
   EG_SNAP(best_mask, unsigned long long) EG_SNAP(bestd_mask, unsigned long long)

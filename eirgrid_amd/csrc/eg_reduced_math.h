@@ -62,6 +62,9 @@ EG_RM void derive_state(DevState& s) {
   s.p_forced = s.stall > 800u ? 1 : 0;
   s.p_stagnation = 1.0 + (0.2 * powd(k / 10.0, 1.8));                                                     // learning.rs:163-164
   s.p_adaptive_lr = s.learning_rate * (1.0 + 0.1 * k);                                                    // learning.rs:174
+  s.boost_others = 1.0 + (s.learning_rate * 0.1); s.boost_noop = 1.0 + s.learning_rate * 0.2;             // learning.rs:74-87
+  s.eps_main = s.stall > 100u ? s.exploration_rate * (1.0 / (1.0 + 0.01 * k)) : s.exploration_rate;       // sampling.rs:150-157
+  s.scaled_power = 1.0 + (2.0 * dmind(k / 1000.0, 3.0));                                                  // sampling.rs:193-195
 }
 
 // apply_contrast_learning in log space (learning.rs:131-255): the boost of one occurrence in the best lists

@@ -1324,13 +1324,13 @@ __device__ __forceinline__ void nudge_after_repair(const DevSnapshot& S, int lan
   const double adj_d = d_improvement > 0.0 ? 1.0 + (lr * d_improvement * 1.5) : 1.0 / (1.0 + (lr * dabs(d_improvement) * 1.5));
   const double combined = S.immediate_weight * w_improvement + (1.0 - S.immediate_weight) * S.rel_improvement;
   const double adj_w = combined > 0.0 ? 1.0 + (lr * combined) : 1.0 / (1.0 + (lr * dabs(combined)));
-  const double boost = 1.0 + (lr * 0.1);
+  const double boost = S.boost_others;
   wave_sync();
   if (lane < EG_N_ACTIONS) {
     double v = SM_W[lane];
     if (lane == action) v = dmin(dmax(v * adj_w, kMinWeight), kMaxWeight);
     else if (combined < 0.0 && lane < kFirstOffset) v = dmin(v * boost, kMaxWeight);
-    if (combined < 0.0 && S.noop_boost && lane == kNothing) v = dmin(v * (1.0 + lr * 0.2), kMaxWeight);
+    if (combined < 0.0 && S.noop_boost && lane == kNothing) v = dmin(v * S.boost_noop, kMaxWeight);
     SM_W[lane] = v;
   }
   if (slot >= 0 && lane < EG_N_DEFICIT) {
@@ -1367,13 +1367,11 @@ __device__ int smart_deficit_fallback(Rng& r, int lane) {   // sampling.rs:492-5
   return 3 * kBattery;
 }
 __device__ int sample_action_weighted(const DevSnapshot& S, Rng& r, Totals& tot, int lane) {   // sampling.rs:147-237
-  const double eps = S.stall > 100u ? S.exploration_rate * (1.0 / (1.0 + 0.01 * (double)S.stall)) : S.exploration_rate;
-  const bool explore = rng_f64(r, lane) < eps;
+  const bool explore = rng_f64(r, lane) < S.eps_main;
   if (explore) return (int)rng_range64(r, lane, (unsigned long long)EG_N_ACTIONS);
   if (S.stall > 500u) {   // sampling.rs:190-220: stable sort by weight descending, weights raised to power_scaling
     if (!tot.scaled_valid) {   // the row was nudged this year: rebuild the table (otherwise it is the host-built one)
-      const double stagnation = dmin((double)S.stall / 1000.0, 3.0);
-      const double power = 1.0 + (2.0 * stagnation);
+      const double power = S.scaled_power;
       wave_sync();
       if (lane < EG_N_ACTIONS) {   // rank of this entry in the stable descending order; x^p by the shared eg_detpow
         const double mine = SM_W[lane];
@@ -1433,11 +1431,22 @@ __device__ __forceinline__ void load_stats_params(const DevSnapshot& S, StatsPar
   P.best_score = st.p_best_score; P.has_best = st.has_lists; P.threshold = st.p_threshold; P.forced = st.p_forced;
   P.adaptive_lr = st.p_adaptive_lr; P.stagnation = st.p_stagnation;
 }
+// (They are the same in every lane but arrive through vector loads: said to be uniform, they live in scalar registers — as
+//  per-lane values the four doubles alone were eight vector registers of the 128 the throughput kernels have, spilled to
+//  scratch and reloaded around every nudge.)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 __device__ __forceinline__ void load_state(DevSnapshot& S) {
   const DevState& st = *S.state();
-  S.learning_rate = st.learning_rate; S.exploration_rate = st.exploration_rate; S.stall = st.stall; S.has_best = st.has_best;
-  S.has_cw = st.has_cw; S.noop_boost = st.noop_boost; S.rel_improvement = st.rel_improvement; S.immediate_weight = st.immediate_weight;
-  S.has_best_actions = st.has_lists; S.has_best_deficit = st.has_lists; S.heur_min = st.heur_min; S.heur_max = st.heur_max;
+  S.learning_rate = uniform_f64(st.learning_rate); S.exploration_rate = uniform_f64(st.exploration_rate);
+  S.stall = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.stall); S.has_best = __builtin_amdgcn_readfirstlane(st.has_best);
+  S.has_cw = __builtin_amdgcn_readfirstlane(st.has_cw); S.noop_boost = __builtin_amdgcn_readfirstlane(st.noop_boost);
+  S.rel_improvement = uniform_f64(st.rel_improvement); S.immediate_weight = uniform_f64(st.immediate_weight);
+  S.has_best_actions = S.has_best_deficit = __builtin_amdgcn_readfirstlane(st.has_lists);
+  S.heur_min = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.heur_min); S.heur_max = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.heur_max);
+  S.boost_others = uniform_f64(st.boost_others); S.boost_noop = uniform_f64(st.boost_noop);
+  S.eps_main = uniform_f64(st.eps_main); S.scaled_power = uniform_f64(st.scaled_power);
 }
 
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
@@ -1614,10 +1623,17 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   if (lane < 8) sm.acc[lane] = 0.0;
   if (lane < 6) sm.yend[lane] = 0.0;
 
-  double np0 = S.pol()[lane], np1 = S.pol()[64 + lane];      // policy row block of year 0; later years are requested a year ahead
+  // The policy row block of a year (128 doubles, + the stalled sampler's tables) goes to LDS at the start of that year.  The
+  // small-batch kernel requests it a year ahead — a lone latency-bound wave with registers to spare.  The throughput kernels
+  // (kHelpers == 0: 128 registers, four waves per SIMD to hide a latency) request it at the start of its own year, ahead of
+  // the year's gathers: held for a year, those seven registers were spilled to scratch and reloaded — the same latency plus
+  // the stores.
+  constexpr bool kRowAhead = kHelpers > 0;
+  double np0 = 0.0, np1 = 0.0;
+  if constexpr (kRowAhead) { np0 = S.pol()[lane]; np1 = S.pol()[64 + lane]; }
   const bool stalled = S.stall > 500u;                        // stalled sampler tables travel the same way
   double ns = 0.0; uint8_t nperm = 0;
-  if (stalled) { ns = S.scaled()[lane]; nperm = S.scaled_perm()[lane]; }
+  if constexpr (kRowAhead) if (stalled) { ns = S.scaled()[lane]; nperm = S.scaled_perm()[lane]; }
   for (int yi = 0; yi < kYears && ep.status == EG_EP_OK; ++yi) {
     const int year = 2025 + yi;
     EG_MARKG(17);
@@ -1627,13 +1643,17 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     const int noff_s = __builtin_amdgcn_readfirstlane(ep.noff);
     const bool carry = ((carry_mask >> yi) & 1u) != 0u;
     const bool sums_from_helper = kHelpers > 0 && yi > 0 && (!kHeavy || helper_sums);
+    if constexpr (!kRowAhead) {      // this year's policy block: requested first, it lands under the gathers below
+      np0 = S.pol()[yi * snap::kPolRow + lane]; np1 = S.pol()[yi * snap::kPolRow + 64 + lane];
+      if (stalled) { ns = S.scaled()[yi * 64 + lane]; nperm = S.scaled_perm()[yi * 64 + lane]; }
+    }
     YearTerms terms;
     if (!sums_from_helper) terms = year_gather(T, lane, yi, ngen_s, noff_s);
-    {  // this year's policy block -> LDS (requested a year ahead), then request next year's
+    {  // this year's policy block -> LDS; small-batch kernel: then request next year's
     wave_sync();
     sm.pol[lane] = np0; sm.pol[64 + lane] = np1;
     if (stalled) { sm.scaled[lane] = ns; sm.ydef[128 + lane] = nperm; }
-    if (yi + 1 < kYears) {
+    if constexpr (kRowAhead) if (yi + 1 < kYears) {
       np0 = S.pol()[(yi + 1) * snap::kPolRow + lane]; np1 = S.pol()[(yi + 1) * snap::kPolRow + 64 + lane];
       if (stalled) { ns = S.scaled()[(yi + 1) * 64 + lane]; nperm = S.scaled_perm()[(yi + 1) * 64 + lane]; }
     }

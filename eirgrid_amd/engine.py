@@ -404,6 +404,12 @@ class Engine:
         N.check(N.lib().eg_timing_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def timing_read_grids(self):
+        """(span ms, sum of the grids' own ms, launches): grids of a batch that ran side by side show span < sum."""
+        span, grids, n = C.c_double(), C.c_double(), C.c_int32()
+        N.check(N.lib().eg_timing_read_grids(self.h, C.byref(span), C.byref(grids), C.byref(n)))
+        return span.value, grids.value, n.value
+
     def update_stats(self, d_stats_ptr: int):
         """Reduce the last launched batch into an int64[STATS_LEN] DEVICE buffer (e.g. torch tensor .data_ptr())."""
         N.check(N.lib().eg_update_stats(self.h, C.c_void_p(d_stats_ptr)), "eg_update_stats")

@@ -178,6 +178,11 @@ int32_t eg_fetch(eg_ctx *, eg_episode_out *out);
 /* HIP-event time of the rollout kernel launches since the last call to eg_timing_reset (milliseconds, count). */
 int32_t eg_timing_reset(eg_ctx *);
 int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
+/* The same launches seen grid by grid.  A batch with replay episodes is up to three grids on two streams (the replay variants
+ * on a side stream, the rest on the null stream): *span_ms = eg_timing_read's total (first start to last end of every batch),
+ * *grids_ms = the replay grids' and the lean grid's own durations added up.  Grids that run side by side: span well below the
+ * sum; grids that were serialised (e.g. two streams sharing one hardware queue): span == sum. */
+int32_t eg_timing_read_grids(eg_ctx *, double *span_ms, double *grids_ms, int32_t *n_launches);
 /* Batch ("reduced") form of the write-locked update (core/multi_simulation.rs:494-508).
  * eg_update_stats reduces the last launched batch on the device into d_stats (EG_STATS_LEN int64, DEVICE pointer, e.g.
  * a torch tensor): integer sums that do not depend on episode / workgroup / rank order, so ONE sum all-reduce over

@@ -184,25 +184,33 @@ def test_bench_line_contract_on_one_gpu():
     assert line["value"] > 0 and abs(line["ms_per_step"] - line["ms_per_batch"] * line["batches_per_step"]) < 1e-6 * line["ms_per_step"]
     cfg = line["config"]
     assert "workload" in cfg and cfg["episodes_failed"] == 0 and cfg["last_batch"]["ok"] == 2048 and cfg["policy"].startswith("pinned")
-    assert cfg["replay"]["best_list_len"] == 28 and cfg["last_batch"]["generators_per_replay_episode"] == 35.0      # config 1's episode, replayed
+    # the headline is the state the training loop sustains (replay episodes have won and doubled the replayed list) ...
+    assert cfg["replay"]["best_list_len"] > 96 and cfg["last_batch"]["generators_per_replay_episode"] > 100
     r = line["roofline"]
     assert r["bound"] and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert "traffic" in r and r["avg_kernel_ms"] > 0
-    g = line["config2_grown"]
-    assert g["value"] > 0 and g["episodes_failed"] == 0 and g["replay"]["best_list_len"] > 96 and g["last_batch"]["generators_per_replay_episode"] > 100
+    assert "traffic" in r and r["avg_kernel_ms"] > 0 and 0.0 < r["frac_requested"] < r["frac"]
+    # counters come from committed profiles and are only quoted for the very library being timed
+    from eirgrid_amd import _native as N
+    assert r["profiles"]["library"] == N.lib().eg_build_hash().decode()
+    if r["traffic"] is None or r["valu_busy"] is None:
+        assert r["counters_not_quoted"] and all("was taken on build" in x for x in r["counters_not_quoted"])
+    # ... the seeded policy (config 1's episode, replayed: SURVEY §8(d) config 3 read literally) is reported beside it
+    g = line["config2_seeded"]
+    assert g["value"] > 0 and g["episodes_failed"] == 0 and g["replay"]["best_list_len"] == 28 and g["last_batch"]["generators_per_replay_episode"] == 35.0
     assert line["config1"]["value"] > 0 and line["config1"]["episodes_failed"] == 0
     c = line["cpu_baseline"]
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "episodes/s" and c["sample"]
 
 
 def test_grids_of_a_batch_overlap_with_a_process_group_up():
-    """The three grids of a batch must run side by side also after torch.distributed has brought RCCL (and its streams) up before
-    the engine exists.  They once did not: the library's side stream shared a hardware queue with the null stream and a batch
-    took 1.69 instead of 1.48 ms.  bench.py with the collectives forced on one rank against the plain run: the exchange itself
-    costs about 1.5 %."""
+    """The grids of a batch must run side by side also after torch.distributed has brought RCCL (and its streams) up before the
+    engine exists.  They once did not: the library's side stream shared a hardware queue with the null stream and a batch took
+    1.69 instead of 1.48 ms.  Shown from the library's own events (eg_timing_read_grids), not from wall-clock differences between
+    runs: with the collectives forced on one rank, a batch's span (first grid's start to last grid's end) must stay well below
+    the grids' own durations added up — serialised grids give span == sum (EIRGRID_SIDE_STREAM=plain reproduces that)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    ms = {}
+    got = {}
     for extra in ((), ("--force-collectives",)):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29561")
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--min-seconds", "0.1",
@@ -210,9 +218,10 @@ def test_grids_of_a_batch_overlap_with_a_process_group_up():
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert line["config"]["episodes_failed"] == 0
-        ms[bool(extra)] = line["ms_per_batch"]
-    print(f"ms per batch: {ms[False]:.3f} plain, {ms[True]:.3f} with RCCL in the loop")
-    assert ms[True] < 1.08 * ms[False]
+        got[bool(extra)] = (line["ms_per_batch"], line["roofline"]["grids"])
+    print("ms per batch / grids:", got)
+    for forced, (ms, grids) in got.items():
+        assert grids["span_ms"] < 0.88 * grids["sum_of_grids_ms"], (forced, grids)
 
 
 def test_train_step_equals_the_stepwise_path(engine):
