@@ -235,6 +235,8 @@ def roofline_object(workload, census, episodes, avg_kernel_s):
     achieved = touched / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     tr, sq = pmc_traffic(workload), sq_counters(workload)
     notes = [x["reason"] for x in (tr, sq) if x and x.get("stale")]
+    if tr is None or sq is None:
+        notes.append(f"no committed counter profile of workload '{workload}' (profiles/*_pmc_hbm_traffic.json, *_sq_counters.json)")
     tr_ok = tr if tr and not tr.get("stale") else None
     sq_ok = sq if sq and not sq.get("stale") else None
     obj = {"bound": "valu-issue/latency (HBM roofline not the limiter: see hbm_frac_measured, valu_busy)",
@@ -255,6 +257,21 @@ def roofline_object(workload, census, episodes, avg_kernel_s):
     if notes:
         obj["counters_not_quoted"] = notes
     return obj
+
+
+def policy_digest(w) -> str:
+    """sha256 over the policy a rank holds after its last update (tables, best lists, counters): equal on every rank when the
+    replicas are identical."""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    for t in w.tables():
+        h.update(np.ascontiguousarray(t).tobytes())
+    for which in (0, 1):
+        h.update(repr(w.lists(which)).encode())
+    for name in ("iterations_without_improvement", "iteration_count", "has_best", "best_net_emissions", "best_opinion", "best_cost", "best_reliability"):
+        h.update(repr(float(w.get(name))).encode())
+    return h.hexdigest()[:16]
 
 
 def workload_key(episodes: int, replay_fraction: float) -> str:
@@ -411,6 +428,10 @@ def main():
             saved_stdout = None
 
     m = measure(trainer, weights, restore_stdout)
+    digests = [policy_digest(weights)]      # (measure() ends with the policy pulled from the device)
+    if use_dist:
+        digests = [None] * world_size
+        dist.all_gather_object(digests, policy_digest(weights))
     wkey = workload_key(args.episodes, args.replay_fraction) + ("grown" if args.grown and args.replay_fraction > 0.0 else "") \
         + ("traj" if args.trajectory else "")
 
@@ -438,6 +459,7 @@ def main():
                        "last_batch": {k: census[k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
                                                              "generators_per_seeded_episode", "generators_per_replay_episode")},
                        "policy": policy_text(args.grown),
+                       "replica_digests": digests,      # the policy every rank holds after the last update: one value when the replicas are identical
                        "replay": m["replay"],
                        **({"strategy_improvements": trainer.improvements,
                            "iterations_without_improvement": int(weights.get("iterations_without_improvement"))} if args.trajectory else {})},

@@ -62,9 +62,14 @@ struct eg_ctx {
   uint8_t* d_snap_held = nullptr;      // eg_policy_hold / eg_policy_rewind
   // the reference's best_result fold (multi_simulation.rs:613-620): 0 = not tracked, 1 = optimization_mode None, 2 = cost_only
   int fold_mode = 0; uint8_t* d_fold = nullptr;
-  // Is the best list long (the replay episodes run the heavy-capable variant and are the batch's long pole)?  As far as the host
-  // knows: from the last upload or pull.  Only the ORDER of the launches depends on it (kernels decide for themselves).
-  bool long_list_hint = false, long_list_hint_held = false;
+  // Is the best list long (the replay episodes run the heavy-capable variant and are the batch's long pole)?  `list_exact`: the host
+  // KNOWS the list the next launch will find on the device (it uploaded, rewound or pulled it and no on-device update has been
+  // enqueued since): the replay variant that has nothing to do is then not launched at all.  Otherwise the device may have replaced
+  // the list since the host last looked — both variants are launched and decide for themselves — and the hint only orders the
+  // launches; it follows the device through `h_list_len`, a pinned host word that k_apply_update and k_rewind write the list's
+  // length to (read without synchronising: as old as the launch queue is deep).
+  bool long_list_hint = false, long_list_hint_held = false, list_exact = false;
+  uint32_t* h_list_len = nullptr; uint32_t* d_list_len = nullptr;      // the same pinned word, host and device address
   DevSnapshot snap{};
   bool snap_valid = false;
   // outputs
@@ -94,6 +99,9 @@ struct eg_ctx {
   // batches of at most this many episodes run the helper-wave kernel (three waves per episode, all resident at once)
   uint32_t helper_max_episodes = 0;
   // heavy episodes (eg_rollout.hip place_heavy): pool of penalty fields, one slot per episode that outgrows kHeavyGens
+  // EIRGRID_HEAVY_POOL_GB (default 64): what the pool may grow to, 126 KB per replay episode of a launch; 131 072 replay episodes
+  // (an all-replay batch of configs[3]'s size) want 16 GB.  eg_memory_report tells what is held.
+  uint32_t heavy_slots_max = uint32_t((size_t(64) << 30) / (size_t(kRadiusClasses) * 2624 * sizeof(double)));
   uint32_t heavy_slots_wanted = 4096, launch_epoch = 0;
   bool heavy_slots_auto = true;      // (EIRGRID_HEAVY_SLOTS fixes the pool size instead)
 };
@@ -152,11 +160,15 @@ int collect_timing(eg_ctx* c, int count = -1) {
 // before every rollout launch: the field pool holds a slot for every heavy episode of the launch (allocated on first use,
 // enlarged when a launch brings more of them: a replay episode without a slot falls back to the exact scan, 20-40x slower,
 // and a launch lasts as long as its slowest episode) and the launch has an epoch of its own
-int prepare_heavy(eg_ctx* c, uint32_t n_heavy) {
+int prepare_heavy(eg_ctx* c, uint32_t n_heavy, bool known_short) {
   constexpr size_t kSlotBytes = size_t(kRadiusClasses) * 2624 * sizeof(double);
+  // No pool while the host KNOWS the best list to be short: replay episodes of a short list never ask for a slot.  (Not by the
+  // pinned hint: the host enqueues a free-running loop many batches ahead of the device, the hint is as old as the queue is deep,
+  // and a long replay episode without a slot takes the exact scan — 33 instead of 5 ms per batch, measured.)
+  if (known_short && !c->dev.heavy) n_heavy = 0;
   uint32_t want = c->heavy_slots_wanted;
-  if (c->heavy_slots_auto && want > 0) {      // 4 096 slots (516 MB) to begin with, then the next power of two, at most 1 M slots = 126 GB
-    while (want < n_heavy && want < (1u << 20) - 1u) want = want * 2u < (1u << 20) ? want * 2u : (1u << 20) - 1u;
+  if (c->heavy_slots_auto && want > 0) {      // 4 096 slots (516 MB) to begin with, then the next power of two, up to the budget
+    while (want < n_heavy && want < c->heavy_slots_max) want = want * 2u < c->heavy_slots_max ? want * 2u : c->heavy_slots_max;
   }
   if (want > 0 && n_heavy > 0 && (!c->dev.heavy || want > c->dev.heavy_slots)) {
     void* pool = nullptr;
@@ -223,7 +235,11 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   const bool split = plan.n_heavy > 0 && plan.n_lean > 0;
   plan.stream_heavy = split ? c->stream_heavy : nullptr;
   plan.stream_lean = nullptr;
-  int rc = prepare_heavy(c, plan.n_heavy);
+  // what the host knows about the best list: exactly (then only the replay variant with work is launched), or from the pinned word
+  bool list_long = c->long_list_hint;
+  if (!c->list_exact && c->h_list_len) list_long = *(volatile uint32_t*)c->h_list_len > uint32_t(kShortReplayMax);
+  plan.skip_long = c->list_exact && !list_long;
+  int rc = prepare_heavy(c, plan.n_heavy, plan.skip_long);
   if (rc != EG_OK) return rc;
   if (split) {
     EG_HIP(hipEventRecord(c->ev_fork[slot], nullptr));
@@ -233,7 +249,7 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
     // the lean grid then waits for an event recorded behind the short-replay variant — which has nothing to do and is gone
     // in microseconds — i.e. until the long variant is being dispatched.  With short replays (or when the host's idea of the
     // list is out of date) nobody waits for anybody.
-    if (c->long_list_hint) plan.go_event = c->ev_go[slot];
+    if (list_long) plan.go_event = c->ev_go[slot];
   }
   const int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, period, d_stats, plan);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -279,7 +295,12 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     // EIRGRID_HEAVY_SLOTS: a fixed number of field slots for heavy episodes (default: 4096 = 516 MB, enlarged to what a launch needs;
     // 0 = every search is the exact scan)
     if (const char* hs = std::getenv("EIRGRID_HEAVY_SLOTS")) { c->heavy_slots_wanted = (uint32_t)std::strtoul(hs, nullptr, 10); c->heavy_slots_auto = false; }
-    if (c->heavy_slots_wanted > (1u << 20) - 1u) c->heavy_slots_wanted = (1u << 20) - 1u;
+    if (const char* hg = std::getenv("EIRGRID_HEAVY_POOL_GB")) {
+      const double gb = std::atof(hg);
+      c->heavy_slots_max = uint32_t(std::min(double((1u << 20) - 1u), std::max(0.0, gb) * double(size_t(1) << 30) / double(size_t(kRadiusClasses) * 2624 * sizeof(double))));
+    }
+    if (c->heavy_slots_max > (1u << 20) - 1u) c->heavy_slots_max = (1u << 20) - 1u;      // (the claim word counts slots in 20 bits)
+    if (c->heavy_slots_wanted > c->heavy_slots_max) c->heavy_slots_wanted = c->heavy_slots_max;
     if (const char* hv = std::getenv("EIRGRID_HELPER_WAVES")) {
       if (std::string(hv) == "0") c->helper_max_episodes = 0;
       else if (std::string(hv) == "all") c->helper_max_episodes = 0xFFFFFFFFu;
@@ -402,6 +423,12 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       set_error("hipMalloc(snapshot) failed"); rc = EG_ERR_HIP;
     } else if (hipMemset(c->d_snap, 0, snap::total) != hipSuccess) { set_error("hipMemset(snapshot) failed"); rc = EG_ERR_HIP; }
   }
+  if (rc == EG_OK) {      // (a convenience, not a requirement: without it the hint stays what the host last knew)
+    if (hipHostMalloc((void**)&c->h_list_len, 64, hipHostMallocMapped) == hipSuccess) {
+      *c->h_list_len = 0u;
+      if (hipHostGetDevicePointer((void**)&c->d_list_len, c->h_list_len, 0) != hipSuccess) { (void)hipGetLastError(); c->d_list_len = nullptr; }
+    } else { (void)hipGetLastError(); c->h_list_len = nullptr; }
+  }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
 }
@@ -415,6 +442,7 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_snap_held) (void)hipFree(c->d_snap_held);
   if (c->d_fold) (void)hipFree(c->d_fold);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
+  if (c->h_list_len) (void)hipHostFree(c->h_list_len);
   if (c->d_mask) (void)hipFree(c->d_mask);
   if (c->d_packet) (void)hipFree(c->d_packet);
   if (c->h_packet) (void)hipHostFree(c->h_packet);
@@ -492,7 +520,8 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
     }
   std::memcpy(h + snap::best_mask, mask, sizeof(mask)); std::memcpy(h + snap::bestd_mask, dmask, sizeof(dmask));
   std::memcpy(h + snap::best_off, off, sizeof(off)); std::memcpy(h + snap::bestd_off, offd, sizeof(offd));
-  c->long_list_hint = have_lists && off[26] > kShortReplayMax;
+  c->long_list_hint = have_lists && off[26] > kShortReplayMax; c->list_exact = true;
+  if (c->h_list_len) *(volatile uint32_t*)c->h_list_len = have_lists ? uint32_t(off[26]) : 0u;
   if (have_lists) { std::memcpy(h + snap::best_actions, s->best_actions, size_t(off[26])); std::memcpy(h + snap::bestd_actions, s->best_deficit_actions, size_t(offd[26])); }
   {  // the policy's scalars as the kernels read them (snap::state)
     DevState st{};
@@ -619,6 +648,14 @@ int32_t eg_fetch_best_run(eg_ctx* c, eg_episode_out* o, int32_t* state) {
   return fetch_records(c->d_snap + snap::best_rec, 1, o);
 }
 
+int32_t eg_memory_report(const eg_ctx* c, uint64_t* table_bytes, uint64_t* record_bytes, uint64_t* field_pool_bytes) {
+  if (!c) return EG_ERR_BAD_ARG;
+  if (table_bytes) *table_bytes = uint64_t(tab::total);
+  if (record_bytes) *record_bytes = uint64_t(c->out_cap) * (rec::stride + sizeof(double));
+  if (field_pool_bytes) *field_pool_bytes = uint64_t(c->dev.heavy ? c->dev.heavy_slots : 0u) * uint64_t(kRadiusClasses) * 2624u * sizeof(double);
+  return EG_OK;
+}
+
 int32_t eg_best_result_track(eg_ctx* c, int32_t mode) {
   if (!c || mode < 0 || mode > 2) { set_error("eg_best_result_track: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
@@ -741,8 +778,9 @@ int device_rollout(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, u
 int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_own_packet, uint64_t noise_seed, bool local_pick) {
   if (!c || !c->snap_valid || !d_packets || n_packets < 1 || !d_own_packet) { set_error("eg_device_apply: bad argument"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
+  c->list_exact = false;      // from here on the device may hold another best list than the host thinks
   int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, c->out, c->last_n, c->last_first,
-                               local_pick && n_packets == 1 && c->last_n > 0, nullptr);
+                               local_pick && n_packets == 1 && c->last_n > 0, c->d_list_len, nullptr);
   if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   lr = launch_stalled_tables(c->d_snap, nullptr);
   if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -755,7 +793,7 @@ int32_t eg_policy_hold(eg_ctx* c) {
   EG_HIP(hipSetDevice(c->device));
   if (!c->d_snap_held) EG_HIP(hipMalloc((void**)&c->d_snap_held, snap::total));
   EG_HIP(hipMemcpyAsync(c->d_snap_held, c->d_snap, snap::total, hipMemcpyDeviceToDevice, nullptr));
-  c->long_list_hint_held = c->long_list_hint;
+  c->long_list_hint_held = c->long_list_hint && c->list_exact;      // (hold is called on a policy the host has just pushed or pulled)
   return EG_OK;
 }
 
@@ -763,9 +801,9 @@ int32_t eg_policy_rewind(eg_ctx* c) {
   if (!c || !c->d_snap_held) { set_error("eg_policy_rewind: nothing held"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
   // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting; one small kernel instead of two copies)
-  const int lr = launch_rewind(c->d_snap, c->d_snap_held, nullptr);
+  const int lr = launch_rewind(c->d_snap, c->d_snap_held, c->d_list_len, nullptr);
   if (lr != 0) { set_error(std::string("k_rewind launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  c->long_list_hint = c->long_list_hint_held;
+  c->long_list_hint = c->long_list_hint_held; c->list_exact = true;      // the next launch finds the held policy's list
   return EG_OK;
 }
 
@@ -784,6 +822,7 @@ int32_t eg_policy_pull(eg_ctx* c, eg_policy* p) {
   }
   p->stall = st.stall; p->iteration_count = st.iteration_count; p->failed_episodes = st.failed_total;
   c->long_list_hint = st.has_lists && reinterpret_cast<const int32_t*>(h.data() + snap::best_off)[EG_YEARS] > kShortReplayMax;
+  c->list_exact = true;      // (the stream was drained above: nothing is in flight that could change it)
   if (st.n_improvements > 0) {      // at least one on-device improvement since the push: the best strategy is the device's
     p->has_best = true; for (int i = 0; i < 4; ++i) p->best_metrics[i] = st.best_metrics[i];
     const int32_t* off = reinterpret_cast<const int32_t*>(h.data() + snap::best_off);

@@ -262,6 +262,7 @@ struct RolloutPlan {
   bool helper_waves;
   void* stream_heavy; void* stream_lean;
   void* go_event;      // not null: recorded on stream_heavy between the two replay variants; the lean grid's stream waits for it
+  bool skip_long;      // the host KNOWS the best list to be short: the long-replay variant (which would return at once) is not launched
   uint32_t n_heavy, n_lean, mode;
   const uint32_t* d_index;
   uint32_t off, period;
@@ -272,11 +273,12 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
 int launch_stalled_tables(uint8_t* d_snap, void* stream);
 // d_snap = d_held, except the count of failed episodes, which goes on counting (eg_policy_rewind)
-int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, void* stream);     // no-op on the device unless state.stall > 500
+// (`list_len_out`: pinned host word, may be null — the length of the best list as the device now holds it, for the host's launch planning)
+int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, uint32_t* list_len_out, void* stream);
 // `o`, n_local, first_index: the batch the own packet came from (the winner's record is kept when it is one of them)
 // local_pick: one packet, made by this device's last batch — the candidate record is built inside the kernel
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
-                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream);
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, uint32_t* list_len_out, void* stream);
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
                  int32_t* d_out_cell, double* d_out_score, void* stream);
 int launch_place_xy(const DevTables& t, int gen_type, int year_index, const double* d_x, const double* d_y, int n, double radius,

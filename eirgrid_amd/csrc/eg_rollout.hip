@@ -666,13 +666,16 @@ template <bool kLong>
 __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, int ngen_s, int noff_s, bool carry, YearTerms t,
                                           YearSums& s, const ListTail& tail) {
   for (int base = 0; base < ngen_s; base += kWave) {
-    if (base > 0) {      // beyond the first 64 generators (rare)
-      if (kLong && base >= kLdsGens) year_gather_gens_tail(T, lane, yi, base, ngen_s, t, tail);
-      else year_gather_gens(T, lane, yi, base, ngen_s, t);
-    }
+    if (!kLong && base > 0) year_gather_gens(T, lane, yi, base, ngen_s, t);      // beyond the first 64 generators (rare)
     const double2 cc = t.g_cc;
     const int ty = t.g_t;
     const double op = (t.g_m03 + t.g_t12) + cc.y;
+    // long-replay variant (hundreds of generators, registers to spare): the next block's terms are requested before this block is
+    // folded — a memory round trip per block and year otherwise, on the serial path of the batch's longest episodes
+    if (kLong && base + kWave < ngen_s) {
+      if (base + kWave >= kLdsGens) year_gather_gens_tail(T, lane, yi, base + kWave, ngen_s, t, tail);
+      else year_gather_gens(T, lane, yi, base + kWave, ngen_s, t);
+    }
     double out = 0.0, co2 = 0.0; int cls = 0;
     if (!carry) { out = sm.type_out[ty]; co2 = sm.type_co2[ty]; cls = (sm.type_info[ty] >> 12) & 3; }
     const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
@@ -2273,7 +2276,7 @@ __device__ void chacha12_block(const uint32_t* key, unsigned long long counter, 
 // the statistics are summed here (integers: any order gives the same sum), the candidate records sit behind them.
 __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const uint8_t* packets, int n_cands, long long* zero_stats,
                                                       unsigned long long noise_seed, const uint8_t* out_base, const double* score_list, uint32_t n_local,
-                                                      unsigned long long first_index, int local_pick) {
+                                                      unsigned long long first_index, int local_pick, uint32_t* list_len_out) {
   constexpr int NA = EG_N_ACTIONS, ND = EG_N_DEFICIT, Y = EG_YEARS;
   constexpr int kMainDraws = Y * NA, kDefDraws = Y * ND, kBlocks = (2 * (kMainDraws + kDefDraws) + 15) / 16;
   __shared__ uint32_t s_noise[kBlocks * 16];
@@ -2504,6 +2507,12 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
   }
   if (tid == 64) { rm::derive_state(st); *gstate = st; }            // beside the row sums of wave 0
+  // the length of the best list goes to a pinned host word: the host plans its launches by it (which replay variant is the long
+  // pole, whether a field pool is needed) without ever waiting for the device
+  if (tid == 65 && list_len_out) {
+    const uint32_t len = st.has_lists ? (uint32_t)(s_improved != 0 ? s_prefix[0][Y] : s_off[0][Y]) : 0u;
+    __hip_atomic_store(list_len_out, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   // this rank's statistics buffer is ready for the next batch's epilogue (when it is also `packets`, every read of it
   // happened before the barriers above)
   __syncthreads();
@@ -2557,7 +2566,9 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
       (void)hipEventRecord((hipEvent_t)p.go_event, (hipStream_t)p.stream_heavy);
       (void)hipStreamWaitEvent((hipStream_t)p.stream_lean, (hipEvent_t)p.go_event, 0);
     }
-    launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, p.ev[1]);
+    // (the short variant's launch carries the start event, the long one's the stop event; without the long one a marker does)
+    if (!p.skip_long) launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, p.ev[1]);
+    else (void)hipEventRecord((hipEvent_t)p.ev[1], (hipStream_t)p.stream_heavy);
   }
   if (p.n_lean > 0) {
     EpisodeMap m{};
@@ -2593,7 +2604,7 @@ int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* st
   hipLaunchKernelGGL(k_fill_lds, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, value, d_sink);
   return (int)hipGetLastError();
 }
-__global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_t* held) {
+__global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_t* held, uint32_t* list_len_out) {
   static_assert(snap::total % 16 == 0 && (snap::state + offsetof(DevState, failed_total)) % 4 == 0, "snapshot layout");
   constexpr uint32_t kFailedWord = (uint32_t)((snap::state + offsetof(DevState, failed_total)) / 4);
   const uint32_t failed = reinterpret_cast<const uint32_t*>(snap_base)[kFailedWord];
@@ -2603,9 +2614,14 @@ __global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_
   for (uint32_t i = threadIdx.x; i < (uint32_t)(snap::total / 16); i += 256u) dst[i] = src[i];
   __syncthreads();
   if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(snap_base)[kFailedWord] = failed;
+  if (threadIdx.x == 64 && list_len_out) {
+    const DevState* hs = reinterpret_cast<const DevState*>(held + snap::state);
+    const uint32_t len = hs->has_lists ? (uint32_t)reinterpret_cast<const int32_t*>(held + snap::best_off)[EG_YEARS] : 0u;
+    __hip_atomic_store(list_len_out, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
-int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, void* stream) {
-  hipLaunchKernelGGL(k_rewind, dim3(1), dim3(256), 0, (hipStream_t)stream, d_snap, d_held);
+int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, uint32_t* list_len_out, void* stream) {
+  hipLaunchKernelGGL(k_rewind, dim3(1), dim3(256), 0, (hipStream_t)stream, d_snap, d_held, list_len_out);
   return (int)hipGetLastError();
 }
 int launch_stalled_tables(uint8_t* d_snap, void* stream) {
@@ -2613,10 +2629,10 @@ int launch_stalled_tables(uint8_t* d_snap, void* stream) {
   return (int)hipGetLastError();
 }
 int launch_apply_update(uint8_t* d_snap, const void* d_packets, int n_packets, long long* d_zero_stats, uint64_t noise_seed,
-                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, void* stream) {
+                        const DevOut& o, uint32_t n_local, uint64_t first_index, bool local_pick, uint32_t* list_len_out, void* stream) {
   hipLaunchKernelGGL(k_apply_update, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, (const uint8_t*)d_packets, n_packets,
                      d_zero_stats, (unsigned long long)noise_seed, (const uint8_t*)o.base, (const double*)o.score_list, n_local, (unsigned long long)first_index,
-                     local_pick ? 1 : 0);
+                     local_pick ? 1 : 0, list_len_out);
   return (int)hipGetLastError();
 }
 int launch_update_stats(const DevSnapshot& s, const DevOut& o, uint32_t n, long long* d_stats, void* stream) {

@@ -404,6 +404,12 @@ class Engine:
         N.check(N.lib().eg_timing_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def memory_report(self):
+        """{tables, records, field_pool} in bytes of device memory (eg_memory_report)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        N.check(N.lib().eg_memory_report(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"tables": a.value, "records": b.value, "field_pool": c.value}
+
     def timing_read_grids(self):
         """(span ms, sum of the grids' own ms, launches): grids of a batch that ran side by side show span < sum."""
         span, grids, n = C.c_double(), C.c_double(), C.c_int32()

@@ -183,6 +183,12 @@ int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
  * *grids_ms = the replay grids' and the lean grid's own durations added up.  Grids that run side by side: span well below the
  * sum; grids that were serialised (e.g. two streams sharing one hardware queue): span == sum. */
 int32_t eg_timing_read_grids(eg_ctx *, double *span_ms, double *grids_ms, int32_t *n_launches);
+/* Device memory the context holds beyond the 50 KB policy: the world's tables (27 MB), the episode records (one of 41.6 KB per
+ * episode of the largest batch so far) and the penalty-field pool of long replay episodes — 126 KB per replay episode of a launch,
+ * allocated with the first replay launch unless the host knows the best list to be short (<= 96 actions: it uploaded, rewound or
+ * pulled it and no on-device update is in flight), grown to the largest launch since, never beyond
+ * EIRGRID_HEAVY_POOL_GB (environment, default 64; an episode without a slot takes the exact scan: slower, same result). */
+int32_t eg_memory_report(const eg_ctx *, uint64_t *table_bytes, uint64_t *record_bytes, uint64_t *field_pool_bytes);
 /* Batch ("reduced") form of the write-locked update (core/multi_simulation.rs:494-508).
  * eg_update_stats reduces the last launched batch on the device into d_stats (EG_STATS_LEN int64, DEVICE pointer, e.g.
  * a torch tensor): integer sums that do not depend on episode / workgroup / rank order, so ONE sum all-reduce over

@@ -101,7 +101,7 @@ def lib():
     L.og_run_episode_tabled.argtypes = [C.POINTER(Tables), C.c_void_p, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(EpisodeOut)]
     L.og_post_episode_update.argtypes = [C.c_void_p, C.c_void_p, dp, C.c_uint64]
     L.og_delay_deficit_probe.restype = C.c_int32
-    L.og_delay_deficit_probe.argtypes = [C.c_void_p, C.c_int32, dp, i32p, dp, i32p]
+    L.og_delay_deficit_probe.argtypes = [C.c_void_p, C.c_int32, dp, i32p, dp, i32p, i32p]
     L.og_reduced_batch_update.restype = C.c_int32
     L.og_reduced_batch_update.argtypes = [C.c_void_p, C.c_int32, i32p, dp, i32p, i32p, u8p, C.c_int32, u8p, C.c_int32,
                                           C.c_uint64, C.POINTER(C.c_int64), i32p]
@@ -293,12 +293,12 @@ def post_episode_update(shared: OracleWeights, local: OracleWeights, metrics, no
 
 
 def delay_deficit_probe(world: OracleWorld, trips: int):
-    """The 2025 repair loop with construction delays on, stopped after `trips` iterations (oracle/eg_oracle.c
-    og_delay_deficit_probe): (status, initial deficit MW, remaining deficit after each trip, active plant after each trip,
-    plants added)."""
-    rem = np.zeros(trips); act = np.zeros(trips, np.int32); d0 = C.c_double(); added = C.c_int32()
-    st = lib().og_delay_deficit_probe(world.h, trips, _dp(rem), act.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(d0), C.byref(added))
-    return st, d0.value, rem, act, added.value
+    """The repair loop of the first year with a deficit, with construction delays on, stopped after `trips` iterations
+    (oracle/eg_oracle.c og_delay_deficit_probe): (status, initial deficit MW, remaining deficit after each trip, active plant after
+    each trip, plants added, year index of that year)."""
+    rem = np.zeros(trips); act = np.zeros(trips, np.int32); d0 = C.c_double(); added = C.c_int32(); year = C.c_int32()
+    st = lib().og_delay_deficit_probe(world.h, trips, _dp(rem), act.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(d0), C.byref(added), C.byref(year))
+    return st, d0.value, rem, act, added.value, year.value
 
 
 STATS_LEN = 8 + 2 * YEARS * NA + YEARS * ND

@@ -1269,22 +1269,39 @@ void og_post_episode_update(og_weights *shared, const og_weights *local, const d
  * (generator.rs:451-480), is_active() is false until it is Operational (generator.rs:519-521), so the added output is 0
  * and remaining_deficit never moves: the reference's `while remaining_deficit > 0.0` (simulation.rs:359) does not end. */
 int32_t og_delay_deficit_probe(const og_world *w, int32_t trips, double *remaining_after_trip, int32_t *active_after_trip,
-                               double *initial_deficit, int32_t *plants_added) {
+                               double *initial_deficit, int32_t *plants_added, int32_t *deficit_year_index) {
   og_episode_out *out = (og_episode_out *)calloc(1, sizeof(*out));
   rec_t rec = {out, 0, trips, remaining_after_trip, active_after_trip};
   map_t map; map_init(&map, w);
   og_weights *p = og_weights_new();
   rng_seed(&p->rng, 12345); p->has_rng = 1;
-  map.enable_delays = 1; map.current_year = OG_BASE_YEAR;
-  map_update_construction_status(&map);
-  action_result s0 = map_state(&map, OG_BASE_YEAR);
-  *initial_deficit = -s0.power_balance;
-  int before = map.ngens;
-  if (s0.power_balance < 0.0) handle_power_deficit(&map, -s0.power_balance, 0, p, &rec);
-  *plants_added = map.ngens - before;
+  map.enable_delays = 1;
+  *initial_deficit = 0.0; *plants_added = 0; *deficit_year_index = -1;
+  /* the year loop of run_simulation (simulation.rs:89-141) without the additional actions, up to the first year with a deficit:
+   * 2025 at HEAD (all existing plant still "Planned", Q1), a later year when the existing plant is operational at the start */
+  for (int yi = 0; yi < OG_YEARS; ++yi) {
+    int year = OG_BASE_YEAR + yi;
+    map.current_year = year;
+    map_update_construction_status(&map);
+    if (year > OG_BASE_YEAR) {
+      for (int s = 0; s < map.S; ++s) {
+        uint32_t new_pop = (uint32_t)round_half_away((double)map.settle[s].pop * 1.01);
+        map.settle[s].pop = new_pop;
+        map.settle[s].usage = (double)new_pop * (0.001 * pow(1.0 + 0.02, (double)(year - OG_BASE_YEAR)));
+      }
+    }
+    action_result s0 = map_state(&map, year);
+    if (s0.power_balance < 0.0) {
+      *initial_deficit = -s0.power_balance; *deficit_year_index = yi;
+      int before = map.ngens;
+      handle_power_deficit(&map, -s0.power_balance, yi, p, &rec);
+      *plants_added = map.ngens - before;
+      break;
+    }
+  }
   int status = rec.overflow;
   og_weights_free(p); map_free(&map); free(out);
-  return status; /* 3: stopped by the trip cap with the deficit still open */
+  return status; /* 3: stopped by the trip cap with the deficit still open; 0: no year has a deficit */
 }
 
 /* ------------------------------------------------------------------------- */

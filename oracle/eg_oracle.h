@@ -114,10 +114,11 @@ int32_t og_run_episode(const og_world *, og_weights *weights, int32_t replay_bes
 void og_post_episode_update(og_weights *shared, const og_weights *local, const double metrics[4],
                             uint64_t noise_seed);
 
-/* N4 evidence: the 2025 repair loop with enable_construction_delays = true, stopped after `trips` iterations; returns 3
- * when the cap stopped it with the deficit still open.  remaining_after_trip / active_after_trip: [trips]. */
+/* N4 evidence: the repair loop of the FIRST YEAR WITH A DEFICIT with enable_construction_delays = true (2025 at HEAD, a later
+ * year when the existing plant is operational at the start), stopped after `trips` iterations; returns 3 when the cap stopped
+ * it with the deficit still open (0: no year has a deficit).  remaining_after_trip / active_after_trip: [trips]. */
 int32_t og_delay_deficit_probe(const og_world *w, int32_t trips, double *remaining_after_trip, int32_t *active_after_trip,
-                               double *initial_deficit, int32_t *plants_added);
+                               double *initial_deficit, int32_t *plants_added, int32_t *deficit_year_index);
 
 /* Batch ("reduced") form of the same update for n episodes that shared one snapshot:
  * independent restatement with libm, the checker of k_apply_update / eg_policy_apply_reduced and of the statistics

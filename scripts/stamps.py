@@ -19,6 +19,11 @@ names = {0: "year-start aggregates", 1: "placement search", 2: "sampling (rng + 
          23: "phase-1 logs + back edge", 24: "glue: before n_add", 25: "glue: loop exit -> metrics", 26: "episode end"}
 tot = st[:, 7].mean()
 print(f"B={B}  mean episode cycles {tot:.0f}  (min {st[:,7].min():.0f} max {st[:,7].max():.0f})  gens/ep {res.n_gens.mean():.1f}")
+# a launch of B <= 1024 episodes (all resident at once) lasts as long as its slowest episode: the spread of the episodes' durations
+cyc = np.sort(st[:, 7])
+print(f"  episode cycles: mean {cyc.mean():.0f}  p50 {cyc[len(cyc) // 2]:.0f}  p90 {cyc[int(0.9 * len(cyc))]:.0f}  p99 {cyc[int(0.99 * len(cyc))]:.0f}  max {cyc[-1]:.0f}"
+      f"  (max / mean {cyc[-1] / cyc.mean():.2f}, p99 / mean {cyc[int(0.99 * len(cyc))] / cyc.mean():.2f});  "
+      f"searches/ep mean {st[:, 11].mean():.1f} max {st[:, 11].max():.0f};  chunks/ep mean {st[:, 8].mean():.1f} max {st[:, 8].max():.0f};  draws/ep mean {res.n_draws.mean():.0f}")
 acc = 0.0
 for i, n in names.items():
     v = st[:, i].mean(); acc += v

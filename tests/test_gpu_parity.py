@@ -552,6 +552,27 @@ def test_heavy_episodes_match_the_oracle(world):
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
 
 
+def test_field_pool_is_only_held_once_the_best_list_is_long(world):
+    """The penalty-field pool of long replay episodes (126 KB per replay episode of a launch) is allocated when the best list is
+    known to be longer than 96 actions, not with the first replay episode: replays of config 1's episode never ask for a slot."""
+    eng = Engine(world, device=0)
+    try:
+        pol = ActionWeights()
+        first = eng.rollout_batch(pol, 12345, 1)
+        pol.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0], first.n_def[0], first.def_log[0])
+        assert sum(len(l) for l in pol.lists(0)) <= 96
+        mask = np.ones(64, np.uint8)
+        a = eng.rollout_batch(pol, 12345, 64, replay_mask=mask)
+        assert (a.status == 0).all() and eng.memory_report()["field_pool"] == 0
+        rng = np.random.default_rng(3)
+        long_pol = _policy_with_best_lists(rng, 9, [0, 4, 12])
+        b = eng.rollout_batch(long_pol, 12345, 64, replay_mask=mask)
+        rep = eng.memory_report()
+        assert (b.status == 0).all() and rep["field_pool"] == 4096 * 6 * 2624 * 8 and rep["tables"] > 20e6 and rep["records"] >= 64 * 41000
+    finally:
+        eng.close()
+
+
 def test_field_pool_grows_with_the_launch(world):
     """More replay episodes in one launch than the field pool starts with (4 096 slots): the pool is enlarged before the launch,
     so none of them falls back to the exact scan (20-40x slower, and a launch lasts as long as its slowest episode), and

@@ -144,10 +144,18 @@ def test_construction_delays_never_close_the_2025_deficit(oracle_world):
     'Planned' (generator.rs:451-480) and is_active() is false until 'Operational' (generator.rs:519-521), so the loop's
     `while remaining_deficit > 0.0` (simulation.rs:359) adds plant after plant without moving the deficit: the reference
     mode does not terminate.  The literal oracle, stopped after 16 trips: 16 plants added, 0 active, deficit unchanged."""
-    status, deficit0, remaining, active, added = O.delay_deficit_probe(oracle_world, 16)
-    assert status == 3 and added == 16
+    status, deficit0, remaining, active, added, year = O.delay_deficit_probe(oracle_world, 16)
+    assert status == 3 and added == 16 and year == 0
     assert deficit0 > 5000.0                      # 2025: all existing plant is still "Planned" (Q1)
     assert (remaining == deficit0).all() and (active == 0).all()
     # the same world without delays closes the deficit in 2025 (config 1's episode finishes)
     st, out = O.run_episode(oracle_world, O.OracleWeights(), 12345)
     assert st == 0 and out.yearly[0][4] >= 0.0
+    # The rejection does not rest on Q1: with the existing plant operational at the start (the README's behaviour) the mode runs until
+    # demand first outgrows the existing plant and hangs there the same way — the plants the repair loop adds are "Planned", the
+    # 59 existing ones stay the only active plant, the deficit does not move.
+    from eirgrid_amd import synthetic_world
+    ow1 = O.OracleWorld(synthetic_world(existing_operational_at_start=True))
+    status, deficit0, remaining, active, added, year = O.delay_deficit_probe(ow1, 16)
+    assert status == 3 and added == 16 and year > 0 and deficit0 > 0.0
+    assert (remaining == deficit0).all() and (active == 59).all()
