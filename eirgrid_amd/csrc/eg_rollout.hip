@@ -154,26 +154,35 @@ __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return (v << n) 
   a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12);           \
   a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7);
 
-// Four consecutive ChaCha12 blocks (rand_chacha fills 64 words per refill), one per lane 0..3.  Not inlined: the
-// episode code draws from ~10 places and the block function is ~1.2k instructions.
+// Four consecutive ChaCha12 blocks (rand_chacha fills 64 words per refill).  Not inlined: the episode code draws from ~10
+// places.  Sixteen lanes work on it: lane 4 b + c holds column c of block b — a word of each of the state's four rows — so a column
+// round is one quarter round per lane, and a diagonal round is the same quarter round after rotating rows 1, 2, 3 by one, two,
+// three lanes inside the quad (DPP quad_perm) and back: 12 + 6 instructions per lane and half-round pair... 180 for the twelve
+// rounds, where one lane per block (four lanes, sixteen words each) took 1 200 — a refill every 32 draws, 2.5 per episode.
+__device__ __forceinline__ uint32_t quad_rot(uint32_t v, int ctrl_is_1230_2301_3012) {
+  // lane i of a quad takes the value of lane (i + k) % 4: quad_perm [1,2,3,0] = 0x39, [2,3,0,1] = 0x4E, [3,0,1,2] = 0x93
+  if (ctrl_is_1230_2301_3012 == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x39, 0xf, 0xf, false);
+  if (ctrl_is_1230_2301_3012 == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x93, 0xf, 0xf, false);
+}
 __device__ __noinline__ void rng_refill(int lane) {
   wave_sync();
-  if (lane < 4) {
-    const unsigned long long counter = sm.rng_counter + (unsigned long long)lane;
-    uint32_t s[16], x[16];
-    s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[4 + i] = sm.rng_key[i];
-    s[12] = (uint32_t)counter; s[13] = (uint32_t)(counter >> 32); s[14] = 0u; s[15] = 0u;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = s[i];
+  if (lane < 16) {
+    const int blk = lane >> 2, col = lane & 3;
+    const unsigned long long counter = sm.rng_counter + (unsigned long long)blk;
+    const uint32_t a0 = col == 0 ? 0x61707865u : (col == 1 ? 0x3320646eu : (col == 2 ? 0x79622d32u : 0x6b206574u));
+    const uint32_t b0 = sm.rng_key[col], c0 = sm.rng_key[4 + col];
+    const uint32_t d0 = col == 0 ? (uint32_t)counter : (col == 1 ? (uint32_t)(counter >> 32) : 0u);
+    uint32_t a = a0, bq = b0, c = c0, d = d0;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      EG_QR(x[0], x[4], x[8], x[12]) EG_QR(x[1], x[5], x[9], x[13]) EG_QR(x[2], x[6], x[10], x[14]) EG_QR(x[3], x[7], x[11], x[15])
-      EG_QR(x[0], x[5], x[10], x[15]) EG_QR(x[1], x[6], x[11], x[12]) EG_QR(x[2], x[7], x[8], x[13]) EG_QR(x[3], x[4], x[9], x[14])
+      EG_QR(a, bq, c, d)                                                    // columns
+      bq = quad_rot(bq, 1); c = quad_rot(c, 2); d = quad_rot(d, 3);        // row k moves k lanes: the diagonals line up as columns
+      EG_QR(a, bq, c, d)                                                    // diagonals
+      bq = quad_rot(bq, 3); c = quad_rot(c, 2); d = quad_rot(d, 1);        // ... and back
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sm.rng[16 * lane + i] = x[i] + s[i];
+    uint32_t* out = sm.rng + 16 * blk + col;
+    out[0] = a + a0; out[4] = bq + b0; out[8] = c + c0; out[12] = d + d0;
   }
   wave_sync();
   if (lane == 0) sm.rng_counter += 4ull;
@@ -617,6 +626,27 @@ __device__ __forceinline__ int list_cell(unsigned long long tail_cells, int gb, 
 //      by lane with readlane, i.e. in list order (year_fold).  Output / CO2 terms of a plant never change (delays off),
 //      so the class sums carry over from the end of last year whenever the existing-plant prefix did (`carry`), bit for
 //      bit; otherwise they are folded here as well. ----
+// acc + x[lane J of the row], in every lane of that row.  gfx90a and later have a DPP form of the VOP2 double-precision
+// multiply-accumulate (row_newbcast only; v_add_f64 is VOP3 and has none): acc = x[J] * 1.0 + acc is that addition — the product is
+// exact and the sum is rounded once — so a sum in list order over 16 lanes is 16 instructions, instead of 16 x (two v_readlane + one
+// add) through scalar registers.  (Inline assembly is opaque to the hazard recogniser: fold_row16 starts with the wait states a DPP
+// read needs after a VALU write of the register or of EXEC.)
+template <int J>
+__device__ __forceinline__ void add_row_lane(double& acc, double x, double one) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(one), "n"(J));
+}
+// acc (the same value in every lane) + x[16 row + 0] + ... + x[16 row + 15], added in that order; valid in the lanes of each row for
+// that row's sixteen values
+__device__ __forceinline__ double fold_row16(double acc, double x) {
+  const double one = 1.0;
+  asm volatile("s_nop 4" ::: "memory");
+  add_row_lane<0>(acc, x, one); add_row_lane<1>(acc, x, one); add_row_lane<2>(acc, x, one); add_row_lane<3>(acc, x, one);
+  add_row_lane<4>(acc, x, one); add_row_lane<5>(acc, x, one); add_row_lane<6>(acc, x, one); add_row_lane<7>(acc, x, one);
+  add_row_lane<8>(acc, x, one); add_row_lane<9>(acc, x, one); add_row_lane<10>(acc, x, one); add_row_lane<11>(acc, x, one);
+  add_row_lane<12>(acc, x, one); add_row_lane<13>(acc, x, one); add_row_lane<14>(acc, x, one); add_row_lane<15>(acc, x, one);
+  return acc;
+}
+
 struct YearTerms { double2 g_cc; double g_m03, g_t12, o_v, o_c; int g_t; };
 struct YearSums { double gcost, optot, offs, ocost, co2, tg, ig, sg; int opcnt; };
 
@@ -679,8 +709,15 @@ __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, 
     double out = 0.0, co2 = 0.0; int cls = 0;
     if (!carry) { out = sm.type_out[ty]; co2 = sm.type_co2[ty]; cls = (sm.type_info[ty] >> 12) & 3; }
     const int cnt = ngen_s - base < kWave ? ngen_s - base : kWave;
-    if (carry) {            // the common year: two independent chains, four generators per trip
+    if (carry) {            // the common year: two independent chains
       int j = 0;
+      {      // sixteen generators at a time through the DPP adder (a row padded with +0.0: sums of positive terms, x + 0.0 == x)
+        const double cz = lane < cnt ? cc.x : 0.0, oz = lane < cnt ? op : 0.0;
+        for (; cnt - j >= 7; j += 16) {      // (below seven generators the scalar path is fewer instructions)
+          const double ag = fold_row16(s.gcost, cz), ao = fold_row16(s.optot, oz);
+          s.gcost = readlane_f64(ag, j); s.optot = readlane_f64(ao, j);      // lane j = the first lane of the row just folded
+        }
+      }
       for (; j + 4 <= cnt; j += 4) {
         const double c0 = readlane_f64(cc.x, j), c1 = readlane_f64(cc.x, j + 1), c2 = readlane_f64(cc.x, j + 2), c3 = readlane_f64(cc.x, j + 3);
         const double o0 = readlane_f64(op, j), o1 = readlane_f64(op, j + 1), o2 = readlane_f64(op, j + 2), o3 = readlane_f64(op, j + 3);
