@@ -391,7 +391,10 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double factor_at(short2v cpk, int gen_packed, int table_offset, int cap) {
   short2v g; __builtin_memcpy(&g, &gen_packed, 4);
   const short2v d = cpk - g;
-  int q = __builtin_amdgcn_sdot2(d, d, 0, false);
+  // (the three-operand form with the constant 0 as its accumulator: from the builtin the compiler makes the two-operand
+  //  accumulating v_dot2c and a v_mov to zero its destination first — one instruction in six of this loop)
+  int q, dbits; __builtin_memcpy(&dbits, &d, 4);
+  asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(q) : "v"(dbits));
   q = q < cap ? q : cap;      // (the class's own radius squared: the table holds 1.0 there)
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + (table_offset + q * 8));
 }
