@@ -342,19 +342,21 @@ __device__ __forceinline__ double wave_max_f64(double v) {
 }
 
 // Inclusive prefix sum over the 64 lanes (DPP: four row shifts, two row broadcasts; a lane without a source adds 0.0).
+// (The shifts say bound_ctrl: a lane whose source lies outside the row reads 0 — no register has to be zeroed first; the
+//  broadcasts only write the rows of their row mask, the others keep the 0 they were given.)
 __device__ __forceinline__ double wave_prefix_sum_f64(double x) {
-#define EG_DPP_ADD_STEP(ctrl, row_mask, bank_mask)                                                                  \
+#define EG_DPP_ADD_STEP(ctrl, row_mask, bank_mask, bound)                                                           \
   {                                                                                                                 \
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, row_mask, bank_mask, false);             \
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, row_mask, bank_mask, false);             \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, row_mask, bank_mask, bound);             \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, row_mask, bank_mask, bound);             \
     x = x + __hiloint2double(hi, lo);                                                                               \
   }
-  EG_DPP_ADD_STEP(0x111, 0xf, 0xf)   // row_shr:1
-  EG_DPP_ADD_STEP(0x112, 0xf, 0xf)   // row_shr:2
-  EG_DPP_ADD_STEP(0x114, 0xf, 0xf)   // row_shr:4
-  EG_DPP_ADD_STEP(0x118, 0xf, 0xf)   // row_shr:8
-  EG_DPP_ADD_STEP(0x142, 0xa, 0xf)   // row_bcast:15 -> rows 1, 3
-  EG_DPP_ADD_STEP(0x143, 0xc, 0xf)   // row_bcast:31 -> rows 2, 3
+  EG_DPP_ADD_STEP(0x111, 0xf, 0xf, true)    // row_shr:1
+  EG_DPP_ADD_STEP(0x112, 0xf, 0xf, true)    // row_shr:2
+  EG_DPP_ADD_STEP(0x114, 0xf, 0xf, true)    // row_shr:4
+  EG_DPP_ADD_STEP(0x118, 0xf, 0xf, true)    // row_shr:8
+  EG_DPP_ADD_STEP(0x142, 0xa, 0xf, false)   // row_bcast:15 -> rows 1, 3
+  EG_DPP_ADD_STEP(0x143, 0xc, 0xf, false)   // row_bcast:31 -> rows 2, 3
 #undef EG_DPP_ADD_STEP
   return x;
 }
