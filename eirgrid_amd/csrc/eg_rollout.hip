@@ -2646,14 +2646,14 @@ int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* st
   hipLaunchKernelGGL(k_fill_lds, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, value, d_sink);
   return (int)hipGetLastError();
 }
-__global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_t* held, uint32_t* list_len_out) {
+__global__ void __launch_bounds__(1024) k_rewind(uint8_t* snap_base, const uint8_t* held, uint32_t* list_len_out) {
   static_assert(snap::total % 16 == 0 && (snap::state + offsetof(DevState, failed_total)) % 4 == 0, "snapshot layout");
   constexpr uint32_t kFailedWord = (uint32_t)((snap::state + offsetof(DevState, failed_total)) / 4);
   const uint32_t failed = reinterpret_cast<const uint32_t*>(snap_base)[kFailedWord];
   __syncthreads();      // (one workgroup: everybody has read the counter before anybody overwrites it)
   const uint4* src = reinterpret_cast<const uint4*>(held);
   uint4* dst = reinterpret_cast<uint4*>(snap_base);
-  for (uint32_t i = threadIdx.x; i < (uint32_t)(snap::total / 16); i += 256u) dst[i] = src[i];
+  for (uint32_t i = threadIdx.x; i < (uint32_t)(snap::total / 16); i += 1024u) dst[i] = src[i];
   __syncthreads();
   if (threadIdx.x == 0) reinterpret_cast<uint32_t*>(snap_base)[kFailedWord] = failed;
   if (threadIdx.x == 64 && list_len_out) {
@@ -2663,7 +2663,7 @@ __global__ void __launch_bounds__(256) k_rewind(uint8_t* snap_base, const uint8_
   }
 }
 int launch_rewind(uint8_t* d_snap, const uint8_t* d_held, uint32_t* list_len_out, void* stream) {
-  hipLaunchKernelGGL(k_rewind, dim3(1), dim3(256), 0, (hipStream_t)stream, d_snap, d_held, list_len_out);
+  hipLaunchKernelGGL(k_rewind, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_snap, d_held, list_len_out);
   return (int)hipGetLastError();
 }
 int launch_stalled_tables(uint8_t* d_snap, void* stream) {
