@@ -1520,28 +1520,50 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
       q_mild = (unsigned long long)llrint(log(1.0 / (1.0 + P.adaptive_lr * combined * 0.5)) * kQ32);   // learning.rs:247
     }
   }
+  // The items are the entries of every year's `current = run ++ deficit` list (learning.rs:196-211), position j of year y against
+  // position j of `best ++ best_deficit` of that year.  Flattened over the years — a lane an item — so that the episode's lists are
+  // read in two memory round trips (the items and the best lists' offsets / masks of their years, then the best-list entries they
+  // are compared with) instead of two per year: this runs at the end of every episode of a training batch, behind nothing to hide it.
   const uint8_t* run = O.run_log(e);
   const uint8_t* def = O.def_log(e);
-  int rp = 0, dp = 0;
-  for (int y = 0; y < EG_YEARS; ++y) {
-    const int nr = O.n_run(e)[y], nd = O.n_def(e)[y];
-    const unsigned long long mask = S.best_mask()[y], dmask = S.bestd_mask()[y];
-    const int b0 = S.best_off()[y], nb = S.best_off()[y + 1] - b0, d0 = S.bestd_off()[y], nbd = S.bestd_off()[y + 1] - d0;
-    for (int j = lane; j < nr + nd; j += kWave) {   // current = run ++ deficit, best = best ++ best_deficit (learning.rs:196-211)
-      const int a = j < nr ? run[rp + j] : def[dp + (j - nr)];
-      if (qualifies) {
-        if (!((mask >> a) & 1ull)) atomicAdd(&st[8 + y * EG_N_ACTIONS + a], q_pen);
-        else if (j < nb + nbd) {
-          const int b = j < nb ? S.best_actions()[b0 + j] : S.bestd_actions()[d0 + (j - nb)];
-          if (a != b) atomicAdd(&st[8 + kStatsMain + y * EG_N_ACTIONS + a], q_mild);
-        }
-      }
-      if (j >= nr && !((dmask >> a) & 1ull)) {        // learning.rs:346-352
-        const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
-        if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
+  int nr = 0, nd = 0;      // lane y: the year's counts
+  if (lane < EG_YEARS) { nr = O.n_run(e)[lane]; nd = O.n_def(e)[lane]; }
+  // exclusive prefix sums over the years (lane y: where year y starts in run_log, in def_log); items of year y start at rp + dp
+  int rp = nr, dp = nd;
+#pragma unroll
+  for (int sh = 1; sh < 32; sh <<= 1) {
+    const int ur = __shfl_up(rp, sh), ud = __shfl_up(dp, sh);
+    if (lane >= sh) { rp += ur; dp += ud; }
+  }
+  const int total = __builtin_amdgcn_readlane(rp, EG_YEARS - 1) + __builtin_amdgcn_readlane(dp, EG_YEARS - 1);
+  rp -= nr; dp -= nd;
+  const int ip = rp + dp;
+  for (int base = 0; base < total; base += kWave) {
+    const int i = base + lane;
+    int y = 0;      // the year of item i: the last year that starts at or before it (empty years share their start with the next one)
+#pragma unroll
+    for (int yy = 1; yy < EG_YEARS; ++yy) y = i >= __builtin_amdgcn_readlane(ip, yy) ? yy : y;
+    // (every lane takes part in the shuffles: a lane masked off would not lend its year's values to the others)
+    const int j = i - __shfl(ip, y), nr_y = __shfl(nr, y), rp_y = __shfl(rp, y), dp_y = __shfl(dp, y);
+    const bool valid = i < total;
+    int a = 0;
+    unsigned long long mask = 0, dmask = 0; int b0 = 0, nb = 0, d0 = 0, nbd = 0;
+    if (valid) {
+      a = j < nr_y ? run[rp_y + j] : def[dp_y + (j - nr_y)];
+      mask = S.best_mask()[y]; dmask = S.bestd_mask()[y];
+      b0 = S.best_off()[y]; nb = S.best_off()[y + 1] - b0; d0 = S.bestd_off()[y]; nbd = S.bestd_off()[y + 1] - d0;
+    }
+    if (valid && qualifies) {
+      if (!((mask >> a) & 1ull)) atomicAdd(&st[8 + y * EG_N_ACTIONS + a], q_pen);
+      else if (j < nb + nbd) {
+        const int b = j < nb ? S.best_actions()[b0 + j] : S.bestd_actions()[d0 + (j - nb)];
+        if (a != b) atomicAdd(&st[8 + kStatsMain + y * EG_N_ACTIONS + a], q_mild);
       }
     }
-    rp += nr; dp += nd;
+    if (valid && j >= nr_y && !((dmask >> a) & 1ull)) {        // learning.rs:346-352
+      const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
+      if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
+    }
   }
 }
 
