@@ -371,6 +371,15 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       next += (cap + 1 + 1) & ~1;      // entries 0..cap, every class starts at an even entry
     }
     if (rc == EG_OK && next > kDrCompact) { set_error("eg_create: radii too large for the compact factor table"); rc = EG_ERR_BAD_ARG; }
+    if (rc == EG_OK) {      // the table as the kernels hold it in LDS (eg_rollout.hip load_factor_table copies it)
+      double* drc = reinterpret_cast<double*>(blob.data() + tab::dr_compact);
+      for (int i = 0; i < kDrCompact; ++i) drc[i] = 1.0;
+      for (int k = 0; k < kRadiusClasses; ++k)
+        for (int ai = 0; ai <= kMaxReach; ++ai) for (int aj = 0; aj <= kMaxReach; ++aj) {
+          const int q = ai * ai + aj * aj;
+          if (q < meta[8 + k]) drc[meta[k] + q] = H.dr[(size_t(k) * 13 + ai) * 13 + aj];
+        }
+    }
   }
   {  // heavy episodes (eg_rollout.hip heavy_add): every (class, di, dj) with a factor below 1, i.e. closer than the class radius
     uint32_t* box = reinterpret_cast<uint32_t*>(blob.data() + tab::hv_box);

@@ -101,7 +101,10 @@ constexpr size_t hv_box = a16(ps + sizeof(PsRec) * size_t(kYears) * kMaxVariants
 // the throughput kernels' factor table in LDS holds every radius class only up to its own radius (eg_rollout.hip load_factor_table):
 // int32 {first entry of class k} [8] | {squared distance from which the factor is 1.0, class k} [8]
 constexpr size_t dr_meta = a16(hv_box + 4 * (1024 + 16));
-constexpr size_t total = dr_meta + 4 * 16;
+// ... and that table itself as the kernels keep it in LDS (f64 [kDrCompact]: class k's factors by squared distance at entries
+// dr_meta[k] .. dr_meta[k] + dr_meta[8 + k], 1.0 everywhere else), so that an episode copies it with one load per lane and block
+constexpr size_t dr_compact = a16(dr_meta + 4 * 16);
+constexpr size_t total = dr_compact + 8 * size_t(kDrCompact);
 }  // namespace tab
 
 struct DevTables {
@@ -121,7 +124,7 @@ struct DevTables {
   EG_TAB(reach, int32_t)
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  EG_TAB(ps, PsRec) EG_TAB(dr_meta, int32_t)
+  EG_TAB(ps, PsRec) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
 #undef EG_TAB
 };
 

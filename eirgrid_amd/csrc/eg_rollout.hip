@@ -271,11 +271,13 @@ __device__ double evaluate_impact(const State& cur, const State& nxt) {   // sco
 __device__ __forceinline__ void load_factor_table(const DevTables& T, int lane) {
   // tails of the staging rows of chunk_product: generators far off the grid (their factor is 1.0), never overwritten
   if (lane < 8) { sm.gstage[0][kWave + lane] = (int)0xC000C000; sm.gstage[1][kWave + lane] = (int)0xC000C000; }
-  for (int i = lane; i < kDrCompact; i += kWave) sm.dr[i] = 1.0;
-  for (int i = lane; i < kRadiusClasses * 169; i += kWave) {
-    const int rc = i / 169, k = i - rc * 169, di = k / 13, dj = k - di * 13, q = di * di + dj * dj;
-    if (q < T.dr_meta()[8 + rc]) sm.dr[T.dr_meta()[rc] + q] = T.dr()[i];
-  }
+  // (the host lays the compact table out as LDS holds it — tab::dr_compact: one independent load per lane and block of 64, one
+  //  memory round trip at the start of an episode where re-indexing the [6][13][13] table here was sixteen dependent ones)
+  double v[(kDrCompact + kWave - 1) / kWave];
+#pragma unroll
+  for (int k = 0; k < (kDrCompact + kWave - 1) / kWave; ++k) v[k] = lane + k * kWave < kDrCompact ? T.dr_compact()[lane + k * kWave] : 1.0;
+#pragma unroll
+  for (int k = 0; k < (kDrCompact + kWave - 1) / kWave; ++k) if (lane + k * kWave < kDrCompact) sm.dr[lane + k * kWave] = v[k];
 }
 // byte offset of a radius class's factors inside the LDS block | its cap << 16: what chunk_product / factor_by_q take as `table`
 // in the throughput kernels (from the type's info word: bits 16-23 cap, 24-31 first entry / 2)
