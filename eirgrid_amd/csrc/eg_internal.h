@@ -104,7 +104,12 @@ constexpr size_t dr_meta = a16(hv_box + 4 * (1024 + 16));
 // ... and that table itself as the kernels keep it in LDS (f64 [kDrCompact]: class k's factors by squared distance at entries
 // dr_meta[k] .. dr_meta[k] + dr_meta[8 + k], 1.0 everywhere else), so that an episode copies it with one load per lane and block
 constexpr size_t dr_compact = a16(dr_meta + 4 * 16);
-constexpr size_t total = dr_compact + 8 * size_t(kDrCompact);
+// the sorted candidates once more as what the approximate scan of the long-replay variant reads of them (eg_rollout.hip place_heavy):
+// the unpenalised score (te * cf) * size_factor and the cell, three registers per chunk in flight instead of eight.  Last, so that the
+// offsets of the tables the lean kernels read stay small.
+constexpr size_t pbase = a16(dr_compact + 8 * size_t(kDrCompact));                     // f64 [26][kMaxVariants][kPsStride]
+constexpr size_t pcell = a16(pbase + 8 * size_t(kYears) * kMaxVariants * kPsStride);     // u32 [26][kMaxVariants][kPsStride]
+constexpr size_t total = pcell + 4 * size_t(kYears) * kMaxVariants * kPsStride;
 }  // namespace tab
 
 struct DevTables {
@@ -124,7 +129,7 @@ struct DevTables {
   EG_TAB(reach, int32_t)
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  EG_TAB(ps, PsRec) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
+  EG_TAB(ps, PsRec) EG_TAB(pbase, double) EG_TAB(pcell, uint32_t) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
 #undef EG_TAB
 };
 

@@ -95,6 +95,7 @@ struct __align__(16) Smem {
   uint32_t yflag; int ysum_opcnt;     // year-start sums folded by the helper wave (sequence number, count)
   double ysum[8];                     //   gcost, optot, offs, ocost, co2, tg, ig, sg
   struct { double score, m03; int cell, pad; } hres[2];
+  double park[18];                    // long-replay variant: the year's aggregates while the field code runs (see k_rollout)
 #ifdef EG_STAMPS
   unsigned long long hdbg[2][4];
 #endif
@@ -1023,11 +1024,22 @@ constexpr int kSearchFallback = -3;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const u32x4 __attribute__((address_space(1)))* GlobalVec4;
 typedef double __attribute__((address_space(1)))* GlobalF64;
+typedef const double __attribute__((address_space(1)))* GlobalF64c;
 __device__ __forceinline__ PsRec load_rec(unsigned long long list_addr, int i) {
   const GlobalVec4 p = (GlobalVec4)(list_addr + (unsigned long long)(unsigned)i * sizeof(PsRec));
   const u32x4 lo = p[0], hi = p[1];
   PsRec r;
   __builtin_memcpy(&r, &lo, 16); __builtin_memcpy(reinterpret_cast<char*>(&r) + 16, &hi, 16);
+  return r;
+}
+// what the approximate scan needs of a record — te and cf (one 16-byte load) and the cell —: five registers per chunk in flight instead of eight
+struct ScanRec { double te, cf; int cell; };
+typedef const int __attribute__((address_space(1)))* GlobalI32c;
+__device__ __forceinline__ ScanRec load_scan_rec(unsigned long long list_addr, int i) {
+  const unsigned long long a = list_addr + (unsigned long long)(unsigned)i * sizeof(PsRec);
+  const u32x4 lo = *(GlobalVec4)a;
+  ScanRec r;
+  __builtin_memcpy(&r, &lo, 16); r.cell = *(GlobalI32c)(a + 24ull);
   return r;
 }
 __device__ __forceinline__ double field_load(GlobalF64 p) {      // past the CU's L1: the wave wrote this entry itself
@@ -1104,7 +1116,7 @@ __device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, unsigne
   return padded / (4 * kWave);
 }
 template <bool kLatency, int kPerLane>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell) {
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int first) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1112,7 +1124,7 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
   const GlobalF64 base = (GlobalF64)field_addr;
   double val[kPerLane], fac[kPerLane]; int off[kPerLane]; uint32_t ens[kPerLane];
 #pragma unroll
-  for (int k = 0; k < kPerLane; ++k) ens[k] = sh.box[k * kWave + lane];
+  for (int k = 0; k < kPerLane; ++k) ens[k] = sh.box[(first + k) * kWave + lane];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all list entries in one LDS round trip, not one after the other)
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k) {
@@ -1138,32 +1150,39 @@ template <bool kLatency>
 __device__ __noinline__ void heavy_build_class(unsigned long long class_addr, unsigned long long tail_cells, int lane, int rc, int table, int reach, int ngen) {
   const GlobalF64 f = (GlobalF64)class_addr;
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
-  double p[kChunks];
+  // blocks per pass over the generator list: all of them with registers to spare (small-batch kernel); three passes of fourteen on
+  // the throughput kernel's 72 registers — it happens six times an episode at most
+  constexpr int kPer = kLatency ? kChunks : 14;
   const int cap = factor_cap<kLatency>(table);
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
+#pragma nounroll
+  for (int c0 = 0; c0 < kChunks; c0 += kPer) {
+    double p[kPer];
 #pragma unroll
-  for (int ch = 0; ch < kChunks; ++ch) p[ch] = 1.0;
-  for (int gb = 0; gb < ngen_s; gb += kWave) {      // the list in blocks of 64, a generator per lane; then one generator at a time
-    const int mine = list_cell(tail_cells, gb, lane, ngen_s, 0);
-    const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
-    for (int j = 0; j < cnt; ++j) {
-      const int gc = __builtin_amdgcn_readlane(mine, j);
-      const int gi = gc / kGrid, gj = gc - gi * kGrid;
-      const int row_lo = gi - reach, row_hi = gi + reach;
+    for (int k = 0; k < kPer; ++k) p[k] = 1.0;
+    for (int gb = 0; gb < ngen_s; gb += kWave) {      // the list in blocks of 64, a generator per lane; then one generator at a time
+      const int mine = list_cell(tail_cells, gb, lane, ngen_s, 0);
+      const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
+      for (int j = 0; j < cnt; ++j) {
+        const int gc = __builtin_amdgcn_readlane(mine, j);
+        const int gi = gc / kGrid, gj = gc - gi * kGrid;
+        const int row_lo = gi - reach, row_hi = gi + reach;
 #pragma unroll
-      for (int ch = 0; ch < kChunks; ++ch) {
-        if ((ch * kWave + kWave - 1) / kGrid < row_lo || (ch * kWave) / kGrid > row_hi) continue;      // uniform: constants against scalars
-        const int cell = ch * kWave + lane;
-        const int ci = cell / kGrid, cj = cell - ci * kGrid;
-        int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
-        q = q < cap ? q : cap;
-        p[ch] = p[ch] * factor_by_q<kLatency>(rc, table, q);
+        for (int k = 0; k < kPer; ++k) {
+          const int ch = c0 + k;      // (uniform; a constant when there is one pass)
+          if ((ch * kWave + kWave - 1) / kGrid < row_lo || (ch * kWave) / kGrid > row_hi) continue;      // uniform: scalars against scalars
+          const int cell = ch * kWave + lane;
+          const int ci = cell / kGrid, cj = cell - ci * kGrid;
+          int q = (ci - gi) * (ci - gi) + (cj - gj) * (cj - gj);
+          q = q < cap ? q : cap;
+          p[k] = p[k] * factor_by_q<kLatency>(rc, table, q);
+        }
       }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
 #pragma unroll
-  for (int ch = 0; ch < kChunks; ++ch) { const int cell = ch * kWave + lane; if (cell < kCells) f[cell] = p[ch]; }
+    for (int k = 0; k < kPer; ++k) { const int cell = (c0 + k) * kWave + lane; if (cell < kCells) f[cell] = p[k]; }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // The reference's product for ONE candidate cell: te times the factor of every generator in list order.  The lanes take a
@@ -1196,8 +1215,12 @@ __device__ __forceinline__ double exact_product_chain(int rc, int table, int nge
 }
 // `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
 // returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
+// Throughput kernel (!kLatency; four waves per SIMD, and this function has 72 registers — k_heavy_register_budget): the scan reads the
+// compact form of the sorted list, `pb_addr` / `pc_addr` = unpenalised score and cell per rank, three registers per chunk in flight
+// instead of eight; the winner's record is one more load by rank.
 template <bool kLatency>
-__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long class_addr, unsigned long long tail_cells, double size_factor, int lane, int rc, int tbl, int ngen) {
+__device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long pb_addr, unsigned long long pc_addr, unsigned long long class_addr,
+                                        unsigned long long tail_cells, double size_factor, int lane, int rc, int tbl, int ngen) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1213,39 +1236,75 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   //    so whatever is within 2^-30 of the final M was so then.  A third one (ties en masse) sends the search to pass 2.
   double M = 0.0; int K = 0;
   double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
-  double q1te = 0.0, q1cf = 1.0, q1m03 = 0.0; int q1cell = 0;      // the record of q1 stays with it: the usual single candidate needs no second load
-  PsRec c[kGroup], nx[kGroup];
+  double q1te = 0.0, q1cf = 1.0; int q1cell = 0;      // small-batch kernel: {te, cf, cell} of q1 stay with it, the usual single candidate needs only its m03 loaded
+  if constexpr (!kLatency) {
+    const GlobalF64c PB = (GlobalF64c)pb_addr; const GlobalI32c PC = (GlobalI32c)pc_addr;
+    double cb[kGroup], nb[kGroup]; int cc[kGroup], nc[kGroup];
 #pragma unroll
-  for (int j = 0; j < kGroup; ++j) c[j] = load_rec(list_addr, j * kWave + lane);
+    for (int j = 0; j < kGroup; ++j) { cb[j] = PB[j * kWave + lane]; cc[j] = PC[j * kWave + lane]; }
+    for (int g = 0; g < kGroups; ++g) {
+      if (g > 0 && !(readlane_f64(cb[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
+      double ap[kGroup];
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) ap[j] = field_load(A + cc[j]);
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) {
+        const int ch = (g + 1) * kGroup + j;
+        nb[j] = 0.0; nc[j] = 0;
+        if (ch < kChunks) { nb[j] = PB[ch * kWave + lane]; nc[j] = PC[ch * kWave + lane]; }
+      }
+      double local = 0.0;
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) { ap[j] = cb[j] * ap[j]; local = dmax(local, ap[j]); }
+      M = dmax(M, wave_max_f64(local));
+      const double thr_now = M * kKeep;
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j)
+        if (ap[j] >= thr_now && ap[j] > 0.0) {
+          const int rank = (g * kGroup + j) * kWave + lane;
+          if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; }
+          else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
+          else over = true;
+        }
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) { cb[j] = nb[j]; cc[j] = nc[j]; }
+      K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
+    }
+  } else {
+  ScanRec c[kGroup], nx[kGroup];
+#pragma unroll
+  for (int j = 0; j < kGroup; ++j) c[j] = load_scan_rec(list_addr, j * kWave + lane);
   for (int g = 0; g < kGroups; ++g) {
-    double base[kGroup], ap[kGroup];
+    double ap[kGroup];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) base[j] = (c[j].te * c[j].cf) * size_factor;
-    if (g > 0 && !(readlane_f64(base[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
+    for (int j = 0; j < kGroup; ++j) ap[j] = (c[j].te * c[j].cf) * size_factor;
+    if (g > 0 && !(readlane_f64(ap[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
+    double fl[kGroup];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) ap[j] = field_load(A + c[j].cell);
+    for (int j = 0; j < kGroup; ++j) fl[j] = field_load(A + c[j].cell);
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int ch = (g + 1) * kGroup + j;
-      nx[j].te = 0.0; nx[j].cf = 1.0; nx[j].m03 = 0.0; nx[j].cell = 0u; nx[j].pad = 0u;
-      if (ch < kChunks) nx[j] = load_rec(list_addr, ch * kWave + lane);
+      nx[j].te = 0.0; nx[j].cf = 1.0; nx[j].cell = 0;
+      if (ch < kChunks) nx[j] = load_scan_rec(list_addr, ch * kWave + lane);
     }
     double local = 0.0;
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) { ap[j] = base[j] * ap[j]; local = dmax(local, ap[j]); }
+    for (int j = 0; j < kGroup; ++j) { ap[j] = ap[j] * fl[j]; local = dmax(local, ap[j]); }
     M = dmax(M, wave_max_f64(local));
     const double thr_now = M * kKeep;
 #pragma unroll
     for (int j = 0; j < kGroup; ++j)
       if (ap[j] >= thr_now && ap[j] > 0.0) {
         const int rank = (g * kGroup + j) * kWave + lane;
-        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1te = c[j].te; q1cf = c[j].cf; q1m03 = c[j].m03; q1cell = (int)c[j].cell; }
+        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1te = c[j].te; q1cf = c[j].cf; q1cell = c[j].cell; }
         else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
         else over = true;
       }
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) c[j] = nx[j];
     K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
+  }
   }
   if (!(M >= 1e-250)) return kSearchFallback;      // (nothing placeable, or subnormal territory: the exact scan decides)
 #ifdef EG_STAMPS
@@ -1284,10 +1343,13 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
 #endif
   ChunkBest b; b.score = 0.0; b.m03 = 0.0; b.cell = kCells;
   if (ncand == 1 && solo >= 0) {      // the usual case: one candidate, its record still in the lane that found it
-    const double te1 = readlane_f64(q1te, solo), cf1 = readlane_f64(q1cf, solo);
-    const int cell1 = __builtin_amdgcn_readlane(q1cell, solo);
+    double te1, cf1; int cell1;
+    if constexpr (kLatency) { te1 = readlane_f64(q1te, solo); cf1 = readlane_f64(q1cf, solo); cell1 = __builtin_amdgcn_readlane(q1cell, solo); }
+    else { const PsRec e1 = load_rec(list_addr, __builtin_amdgcn_readlane(q1r, solo)); te1 = e1.te; cf1 = e1.cf; cell1 = (int)e1.cell; b.m03 = e1.m03; }
+    // (its m03 is requested before the product: it lands under it)
+    if constexpr (kLatency) b.m03 = *(GlobalF64c)(list_addr + (unsigned long long)(unsigned)__builtin_amdgcn_readlane(q1r, solo) * sizeof(PsRec) + 16ull);
     b.score = (exact_product_chain<kLatency>(rc, tbl, ngen_s, te1, cell1, lane, tail_cells) * cf1) * size_factor;
-    b.cell = cell1; b.m03 = readlane_f64(q1m03, solo);
+    b.cell = cell1;
   } else if (ncand <= 4 || ngen_s > kLdsGens) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
                                                      // (chunk_product below walks the on-chip window only)
     for (int k = 0; k < ncand; ++k) {
@@ -1613,16 +1675,31 @@ __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b)
 // is only the device knows (an on-device update may have replaced it since the host last looked), and the host plans
 // launches many batches ahead of the device.
 constexpr int kLean = 0, kReplayShort = 1, kReplayLong = 2;
+// This file is compiled twice (csrc/Makefile).  eg_rollout.o holds the small-batch kernels (an episode wave and a helper wave) and
+// everything that is not a rollout; eg_rollout_tp.o (-DEG_TU_THROUGHPUT) holds the three throughput kernels k_rollout<0, kind>,
+// compiled WITHOUT machine-code loop-invariant code motion.  Out of the year and action loops that pass hoists literal constants and
+// table addresses into registers — which are then live for the whole episode and across the calls of the field code: the long-replay
+// variant takes 157 vector registers with it and 126 without, i.e. four waves per SIMD instead of two (with its aggregates parked in
+// LDS around those calls and the field code held to 72 registers, k_heavy_register_budget), so that two long replays leave a SIMD room
+// for two lean waves; the lean variant takes 120 instead of 128 + a spill.  Measured (profiles/r03_ab_notes.log): the sustained batch
+// 3.07 -> 2.62 ms; 16 384 sampled episodes alone +1.3 %, the seeded batch +1.1 %; the small-batch kernel would lose 3.6 % and keeps
+// the pass: hence two objects, and not a flag for the file.
+#ifdef EG_TU_THROUGHPUT
+#define EG_HEAVY_WAVES 4
+#else
+#define EG_HEAVY_WAVES 2
+#endif
 // actions in the best list up to which replay episodes stay on the exact scan (measured at 16 384 x 10 %: a batch with an
 // 82-action list — 90 generators per replay episode — takes 2.02 ms this side of the limit and 2.37 ms on the other, one
 // with a 109-action list — 117 generators — 2.39 against 2.25)
 // (kShortReplayMax = 96, eg_internal.h)
 template <int kHelpers, int kKind>
-__global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? 2 : (kHelpers > 0 ? 3 : 4)) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
+__global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ? (kHelpers > 0 ? 2 : EG_HEAVY_WAVES) : (kHelpers > 0 ? 3 : 4)) k_rollout(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long seed,
                                                                     unsigned long long first_index, uint32_t n_episodes,
                                                                     const uint8_t* __restrict__ replay_mask, uint32_t replay_period,
                                                                     long long* stats, EpisodeMap emap) {
   constexpr bool kHeavy = kKind == kReplayLong, kReplay = kKind != kLean;
+  constexpr bool kPark = kHeavy && kHelpers == 0 && EG_HEAVY_WAVES >= 4;
   const int lane = threadIdx.x & (kWave - 1);
   if (blockIdx.x >= emap.count) return;
   if constexpr (kReplay) {      // (uniform for the whole grid)
@@ -1893,6 +1970,19 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         double m03v = 0.0;
         int cell = -1;
         bool placed = false;
+        // Long-replay variant at four waves per SIMD: the field code below is not inlined, and what is live across a call has to fit
+        // beside the callee's registers.  The year's aggregates — thirty-odd registers of uniform doubles — wait in LDS from here until
+        // the field update has been issued.
+        if constexpr (kPark) {
+          wave_sync();
+          if (lane == 0) {
+            sm.park[0] = a.co2; sm.park[1] = a.tg; sm.park[2] = a.ig; sm.park[3] = a.sg; sm.park[4] = a.optot; sm.park[5] = a.gcost; sm.park[6] = a.ocost;
+            sm.park[7] = a.gcost_prev; sm.park[8] = a.ocost_prev; sm.park[9] = a.offs; sm.park[10] = a.usage;
+            sm.park[11] = cur.net; sm.park[12] = cur.opinion; sm.park[13] = cur.balance; sm.park[14] = cur.cost; sm.park[15] = remaining;
+            sm.park[16] = __hiloint2double(0, a.opcnt);
+          }
+          wave_sync();
+        }
         if constexpr (kHeavy) if (ep.ngen >= kHeavyGens && ep.heavy != -2) {      // a long list: approximate field + exact evaluation of the few candidates
           const unsigned long long slot_bytes = (unsigned long long)(kRadiusClasses * kFieldStride) * 8ull;
           if (ep.heavy == -1) ep.heavy = heavy_claim(T, lane);
@@ -1908,7 +1998,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
 #endif
-            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + (size_t)(yi * kMaxVariants + hv) * kPsStride), class_addr,
+            const size_t yv = (size_t)(yi * kMaxVariants + hv) * kPsStride;
+            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + yv), (unsigned long long)(T.pbase() + yv), (unsigned long long)(T.pcell() + yv), class_addr,
                                                         tail.gen_cell, T.size_factor, lane, hrc, throughput_table(info), ep.ngen);
 #ifdef EG_STAMPS
             const unsigned long long th1 = __builtin_readcyclecounter();
@@ -1937,6 +2028,32 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
 #endif
         }
         EG_T1(1);
+        // the field of every class the episode keeps, for the new generator — requested here, ahead of the bookkeeping, so that it is
+        // one call region with the search (the aggregates are parked once); eight list entries per lane and call
+        if constexpr (kHeavy) if (cell >= 0 && ep.ngen < kGenCap && ep.heavy_classes != 0) {
+          const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
+          ep.chunks += 2 * ep.heavy_quads;      // 256 entries of 8 B read and written per quad = 2 units of 2 KB
+          if constexpr (kHelpers > 0) {
+            switch (ep.heavy_quads) {      // (uniform)
+              case 1: heavy_add<true, 4>(field_addr, lane, cell, 0); break;
+              case 2: heavy_add<true, 8>(field_addr, lane, cell, 0); break;
+              case 3: heavy_add<true, 12>(field_addr, lane, cell, 0); break;
+              default: heavy_add<true, 16>(field_addr, lane, cell, 0); break;
+            }
+          } else {
+            if (ep.heavy_quads == 1) heavy_add<false, 4>(field_addr, lane, cell, 0);
+            else heavy_add<false, 8>(field_addr, lane, cell, 0);
+            if (ep.heavy_quads == 3) heavy_add<false, 4>(field_addr, lane, cell, 8);
+            else if (ep.heavy_quads >= 4) heavy_add<false, 8>(field_addr, lane, cell, 8);
+          }
+        }
+        if constexpr (kPark) {
+          wave_sync();
+          a.co2 = sm.park[0]; a.tg = sm.park[1]; a.ig = sm.park[2]; a.sg = sm.park[3]; a.optot = sm.park[4]; a.gcost = sm.park[5]; a.ocost = sm.park[6];
+          a.gcost_prev = sm.park[7]; a.ocost_prev = sm.park[8]; a.offs = sm.park[9]; a.usage = sm.park[10];
+          cur.net = sm.park[11]; cur.opinion = sm.park[12]; cur.balance = sm.park[13]; cur.cost = sm.park[14]; remaining = sm.park[15];
+          a.opcnt = __double2loint(sm.park[16]);
+        }
         if (cell < 0) { ep.status = cell == kSearchLost ? EG_EP_INTERNAL : EG_EP_NO_LOCATION; break; }   // actions.rs:77-89 is unreachable here (Q16)
         EG_MARKG(21);
         if (ep.ngen >= kGenCap) { ep.status = EG_EP_OVERFLOW; break; }
@@ -1958,16 +2075,6 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         if (cls == 1) a.ig += out; else if (cls == 2) a.sg += out; else a.tg += out;
         a.optot += (m03v + t12v) + ccv.y;
         a.opcnt += 1;
-        if constexpr (kHeavy) if (ep.heavy_classes != 0) {
-          const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
-          ep.chunks += 2 * ep.heavy_quads;      // 256 entries of 8 B read and written per quad = 2 units of 2 KB
-          switch (ep.heavy_quads) {      // (uniform)
-            case 1: heavy_add<(kHelpers > 0), 4>(field_addr, lane, cell); break;
-            case 2: heavy_add<(kHelpers > 0), 8>(field_addr, lane, cell); break;
-            case 3: heavy_add<(kHelpers > 0), 12>(field_addr, lane, cell); break;
-            default: heavy_add<(kHelpers > 0), 16>(field_addr, lane, cell); break;
-          }
-        }
         if constexpr (kHelpers > 0) {      // the searches of both waves read the list from here (chunk_product_latency)
           // (the helper may still be evaluating its chunk of the search that just ended: it masks what lies behind the
           //  list it was given, chunk_product_latency<true>, so the new entry may appear under it)
@@ -2130,6 +2237,23 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   }
 }
 
+#ifdef EG_TU_THROUGHPUT
+// Never launched.  A device function's register budget is the tightest launch bound among the kernels that can reach it, and the
+// attributes that would say so directly are for kernels only: this kernel's bound of seven waves per SIMD gives the long-replay
+// variant's field code 72 registers, which — with the episode's aggregates parked in LDS around those calls — is what lets that
+// variant run four waves per SIMD (128 registers) beside the lean grid.
+__global__ void __launch_bounds__(kWave, 7) k_heavy_register_budget(unsigned long long a, unsigned long long b, unsigned long long c, double d, int i, int* out) {
+  const int lane = threadIdx.x;
+  int r = place_heavy<false>(a, b, c, a + b, b + c, d, lane, i, i, i);
+  r += place_exact_long<false>(a, c, d, lane, i, i, i);
+  heavy_build_class<false>(a, c, lane, i, i, i, i);
+  r += heavy_pack_list<false>(a, b, lane, i);
+  heavy_add<false, 4>(a, lane, i, i); heavy_add<false, 8>(a, lane, i, i);
+  out[lane] = r;
+}
+#endif
+
+#ifndef EG_TU_THROUGHPUT      // (everything from here to the launchers lives in eg_rollout.o only)
 // ---- B2: a single placement search, for parity tests of the arg-max --------------------------------------------
 __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, const uint16_t* __restrict__ cells,
                                                  int n_extra, int32_t* out_cell, double* out_score) {
@@ -2598,20 +2722,39 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 #endif
 }
 
+#endif      // EG_TU_THROUGHPUT
 }  // namespace
 
+// the throughput kernels (one wave per episode), from their own object (see the top of the kernel section)
+int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
+                              const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
+                              const uint32_t* index, uint32_t off, uint32_t period, void* stream, void* ev0, void* ev1);
+#ifdef EG_TU_THROUGHPUT
+int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
+                              const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
+                              const uint32_t* index, uint32_t off, uint32_t period, void* stream, void* ev0, void* ev1) {
+  EpisodeMap map{};
+  map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period;
+  // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
+#define EG_LAUNCH_TP(kKind) hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, \
+                                                  t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map)
+  if (kind == kReplayLong) EG_LAUNCH_TP(kReplayLong);
+  else if (kind == kReplayShort) EG_LAUNCH_TP(kReplayShort);
+  else EG_LAUNCH_TP(kLean);
+#undef EG_LAUNCH_TP
+  return (int)hipGetLastError();
+}
+#else
 namespace {
 template <int kKind>
 void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                     const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const EpisodeMap& map, void* stream, void* ev0, void* ev1) {
-  // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
   if (helper_waves)
     hipExtLaunchKernelGGL((k_rollout<kHelperWaves, kKind>), dim3(map.count), dim3(kWave * (1 + kHelperWaves)), 0, (hipStream_t)stream,
                           (hipEvent_t)ev0, (hipEvent_t)ev1, 0, t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n,
                           d_replay_mask, replay_period, d_stats, map);
   else
-    hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
-                          t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map);
+    (void)launch_rollout_throughput(kKind, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, map.count, map.mode, map.index, map.off, map.period, stream, ev0, ev1);
 }
 }  // namespace
 
@@ -2715,5 +2858,7 @@ int launch_pick_best(const DevOut& o, uint32_t n, uint64_t first_index, UpdateCa
   hipLaunchKernelGGL(k_pick_best, dim3(1), dim3(1024), 0, (hipStream_t)stream, o, n, (unsigned long long)first_index, d_cand);
   return (int)hipGetLastError();
 }
+
+#endif      // EG_TU_THROUGHPUT
 
 }  // namespace eg
