@@ -1115,8 +1115,11 @@ __device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, unsigne
   wave_sync();
   return padded / (4 * kWave);
 }
+// Throughput kernel: inlined.  A function that is not waits for its stores to be acknowledged before it returns (s_waitcnt vmcnt(0) ahead of
+// s_setpc), and waits on entry for whatever its caller had in flight: as a call, the update cost the episode its own loads, then its
+// stores' round trip, and before that the cost terms the caller had just requested — three exposed latencies where one is needed.
 template <bool kLatency, int kPerLane>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int first) {
+__device__ __forceinline__ void heavy_add_body(unsigned long long field_addr, int lane, int cell, int first) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1142,6 +1145,8 @@ __device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, 
   if (lane == 0) sm.hdbg[0][3] += __builtin_readcyclecounter() - ts0;
 #endif
 }
+template <bool kLatency, int kPerLane>
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int first) { heavy_add_body<kLatency, kPerLane>(field_addr, lane, cell, first); }
 // A class joins: its field = for every cell the product of the factors of the generators placed so far (any order: the
 // field only serves a bound).  The field of the 41 blocks of 64 cells sits in registers while the generators pass by; a
 // generator only touches the blocks whose rows come within `reach` of its own row (a scalar test per block).
@@ -1228,7 +1233,10 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   const GlobalF64 A = (GlobalF64)class_addr;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;      // 41: the list holds exactly kChunks * 64 records
-  constexpr int kGroup = 4, kGroups = (kChunks + kGroup - 1) / kGroup;
+#ifndef EG_SCAN_GROUP
+#define EG_SCAN_GROUP 4
+#endif
+  constexpr int kGroup = kLatency ? 4 : EG_SCAN_GROUP, kGroups = (kChunks + kGroup - 1) / kGroup;
   constexpr double kKeep = 1.0 - 0x1p-30;
   // 1. largest approximate score M, scanning in descending order of the unpenalised score, four chunks per memory round
   //    trip (the records of the next group are requested while this group's field entries are on their way).  A lane
@@ -1238,20 +1246,27 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
   double q1te = 0.0, q1cf = 1.0; int q1cell = 0;      // small-batch kernel: {te, cf, cell} of q1 stay with it, the usual single candidate needs only its m03 loaded
   if constexpr (!kLatency) {
-    const GlobalF64c PB = (GlobalF64c)pb_addr; const GlobalI32c PC = (GlobalI32c)pc_addr;
+    // (the addresses are the same in every lane: as scalar registers they leave every request a 32-bit lane offset — the 72 registers of
+    //  this function have no room for an address pair per request)
+    auto uniform_u64 = [](unsigned long long a) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a); };
+    const unsigned long long pb_s = uniform_u64(pb_addr), pc_s = uniform_u64(pc_addr), a_s = uniform_u64(class_addr);
+    auto pb_at = [&](int r) { return *(GlobalF64c)(pb_s + (unsigned long long)((unsigned)r * 8u)); };
+    auto pc_at = [&](int r) { return *(GlobalI32c)(pc_s + (unsigned long long)((unsigned)r * 4u)); };
+    auto field_at = [&](int cell) { return __hip_atomic_load((GlobalF64)(a_s + (unsigned long long)((unsigned)cell * 8u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     double cb[kGroup], nb[kGroup]; int cc[kGroup], nc[kGroup];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) { cb[j] = PB[j * kWave + lane]; cc[j] = PC[j * kWave + lane]; }
+    for (int j = 0; j < kGroup; ++j) { cb[j] = pb_at(j * kWave + lane); cc[j] = pc_at(j * kWave + lane); }
+#pragma nounroll
     for (int g = 0; g < kGroups; ++g) {
       if (g > 0 && !(readlane_f64(cb[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
       double ap[kGroup];
 #pragma unroll
-      for (int j = 0; j < kGroup; ++j) ap[j] = field_load(A + cc[j]);
+      for (int j = 0; j < kGroup; ++j) ap[j] = field_at(cc[j]);
 #pragma unroll
       for (int j = 0; j < kGroup; ++j) {
         const int ch = (g + 1) * kGroup + j;
         nb[j] = 0.0; nc[j] = 0;
-        if (ch < kChunks) { nb[j] = PB[ch * kWave + lane]; nc[j] = PC[ch * kWave + lane]; }
+        if (ch < kChunks) { nb[j] = pb_at(ch * kWave + lane); nc[j] = pc_at(ch * kWave + lane); }
       }
       double local = 0.0;
 #pragma unroll
@@ -2041,10 +2056,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
               default: heavy_add<true, 16>(field_addr, lane, cell, 0); break;
             }
           } else {
-            if (ep.heavy_quads == 1) heavy_add<false, 4>(field_addr, lane, cell, 0);
-            else heavy_add<false, 8>(field_addr, lane, cell, 0);
-            if (ep.heavy_quads == 3) heavy_add<false, 4>(field_addr, lane, cell, 8);
-            else if (ep.heavy_quads >= 4) heavy_add<false, 8>(field_addr, lane, cell, 8);
+            if (ep.heavy_quads == 1) heavy_add_body<false, 4>(field_addr, lane, cell, 0);
+            else heavy_add_body<false, 8>(field_addr, lane, cell, 0);
+            if (ep.heavy_quads == 3) heavy_add_body<false, 4>(field_addr, lane, cell, 8);
+            else if (ep.heavy_quads >= 4) heavy_add_body<false, 8>(field_addr, lane, cell, 8);
           }
         }
         if constexpr (kPark) {
@@ -2248,7 +2263,6 @@ __global__ void __launch_bounds__(kWave, 7) k_heavy_register_budget(unsigned lon
   r += place_exact_long<false>(a, c, d, lane, i, i, i);
   heavy_build_class<false>(a, c, lane, i, i, i, i);
   r += heavy_pack_list<false>(a, b, lane, i);
-  heavy_add<false, 4>(a, lane, i, i); heavy_add<false, 8>(a, lane, i, i);
   out[lane] = r;
 }
 #endif
