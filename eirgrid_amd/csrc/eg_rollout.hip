@@ -1032,16 +1032,7 @@ __device__ __forceinline__ PsRec load_rec(unsigned long long list_addr, int i) {
   __builtin_memcpy(&r, &lo, 16); __builtin_memcpy(reinterpret_cast<char*>(&r) + 16, &hi, 16);
   return r;
 }
-// what the approximate scan needs of a record — te and cf (one 16-byte load) and the cell —: five registers per chunk in flight instead of eight
-struct ScanRec { double te, cf; int cell; };
 typedef const int __attribute__((address_space(1)))* GlobalI32c;
-__device__ __forceinline__ ScanRec load_scan_rec(unsigned long long list_addr, int i) {
-  const unsigned long long a = list_addr + (unsigned long long)(unsigned)i * sizeof(PsRec);
-  const u32x4 lo = *(GlobalVec4)a;
-  ScanRec r;
-  __builtin_memcpy(&r, &lo, 16); r.cell = *(GlobalI32c)(a + 24ull);
-  return r;
-}
 __device__ __forceinline__ double field_load(GlobalF64 p) {      // past the CU's L1: the wave wrote this entry itself
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1219,10 +1210,10 @@ __device__ __forceinline__ double exact_product_chain(int rc, int table, int nge
   return s;
 }
 // `list_addr`: the sorted candidate list of (year, variant); `class_addr`: the field of the radius class.
-// returns cell | chunks requested << 16, or kSearchFallback; the winner's 0.03 * mean settlement opinion in sm.hres[1].m03
-// Throughput kernel (!kLatency; four waves per SIMD, and this function has 72 registers — k_heavy_register_budget): the scan reads the
-// compact form of the sorted list, `pb_addr` / `pc_addr` = unpenalised score and cell per rank, three registers per chunk in flight
-// instead of eight; the winner's record is one more load by rank.
+// returns cell | chunks requested << 16, or kSearchFallback (the winner's 0.03 * mean settlement opinion: the caller reads tab::m03)
+// The scan reads the compact form of the sorted list, `pb_addr` / `pc_addr` = unpenalised score and cell per rank: three registers per
+// chunk in flight instead of the eight of a full record (in the throughput kernel — four waves per SIMD — this function has 72
+// registers, k_heavy_register_budget); the full records are only read for candidates that tie.
 template <bool kLatency>
 __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned long long pb_addr, unsigned long long pc_addr, unsigned long long class_addr,
                                         unsigned long long tail_cells, double size_factor, int lane, int rc, int tbl, int ngen) {
@@ -1230,13 +1221,12 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last field update's stores are in L2 before anything gathers
-  const GlobalF64 A = (GlobalF64)class_addr;
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;      // 41: the list holds exactly kChunks * 64 records
 #ifndef EG_SCAN_GROUP
 #define EG_SCAN_GROUP 4
 #endif
-  constexpr int kGroup = kLatency ? 4 : EG_SCAN_GROUP, kGroups = (kChunks + kGroup - 1) / kGroup;
+  constexpr int kGroup = EG_SCAN_GROUP, kGroups = (kChunks + kGroup - 1) / kGroup;
   constexpr double kKeep = 1.0 - 0x1p-30;
   // 1. largest approximate score M, scanning in descending order of the unpenalised score, four chunks per memory round
   //    trip (the records of the next group are requested while this group's field entries are on their way).  A lane
@@ -1244,82 +1234,45 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   //    so whatever is within 2^-30 of the final M was so then.  A third one (ties en masse) sends the search to pass 2.
   double M = 0.0; int K = 0;
   double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
-  double q1te = 0.0, q1cf = 1.0; int q1cell = 0;      // small-batch kernel: {te, cf, cell} of q1 stay with it, the usual single candidate needs only its m03 loaded
-  if constexpr (!kLatency) {
-    // (the addresses are the same in every lane: as scalar registers they leave every request a 32-bit lane offset — the 72 registers of
-    //  this function have no room for an address pair per request)
-    auto uniform_u64 = [](unsigned long long a) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a); };
-    const unsigned long long pb_s = uniform_u64(pb_addr), pc_s = uniform_u64(pc_addr), a_s = uniform_u64(class_addr);
-    auto pb_at = [&](int r) { return *(GlobalF64c)(pb_s + (unsigned long long)((unsigned)r * 8u)); };
-    auto pc_at = [&](int r) { return *(GlobalI32c)(pc_s + (unsigned long long)((unsigned)r * 4u)); };
-    auto field_at = [&](int cell) { return __hip_atomic_load((GlobalF64)(a_s + (unsigned long long)((unsigned)cell * 8u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    double cb[kGroup], nb[kGroup]; int cc[kGroup], nc[kGroup];
+  int q1cell = 0;      // the cell of q1 stays with it: the usual single candidate needs nothing else
+  // (the addresses are the same in every lane: as scalar registers they leave every request a 32-bit lane offset — the 72 registers of
+  //  this function have no room for an address pair per request)
+  auto uniform_u64 = [](unsigned long long a) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a); };
+  const unsigned long long pb_s = uniform_u64(pb_addr), pc_s = uniform_u64(pc_addr), a_s = uniform_u64(class_addr);
+  auto pb_at = [&](int r) { return *(GlobalF64c)(pb_s + (unsigned long long)((unsigned)r * 8u)); };
+  auto pc_at = [&](int r) { return *(GlobalI32c)(pc_s + (unsigned long long)((unsigned)r * 4u)); };
+  auto field_at = [&](int cell) { return __hip_atomic_load((GlobalF64)(a_s + (unsigned long long)((unsigned)cell * 8u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  double cb[kGroup], nb[kGroup]; int cc[kGroup], nc[kGroup];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) { cb[j] = pb_at(j * kWave + lane); cc[j] = pc_at(j * kWave + lane); }
+  for (int j = 0; j < kGroup; ++j) { cb[j] = pb_at(j * kWave + lane); cc[j] = pc_at(j * kWave + lane); }
 #pragma nounroll
-    for (int g = 0; g < kGroups; ++g) {
-      if (g > 0 && !(readlane_f64(cb[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
-      double ap[kGroup];
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) ap[j] = field_at(cc[j]);
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) {
-        const int ch = (g + 1) * kGroup + j;
-        nb[j] = 0.0; nc[j] = 0;
-        if (ch < kChunks) { nb[j] = pb_at(ch * kWave + lane); nc[j] = pc_at(ch * kWave + lane); }
-      }
-      double local = 0.0;
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) { ap[j] = cb[j] * ap[j]; local = dmax(local, ap[j]); }
-      M = dmax(M, wave_max_f64(local));
-      const double thr_now = M * kKeep;
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j)
-        if (ap[j] >= thr_now && ap[j] > 0.0) {
-          const int rank = (g * kGroup + j) * kWave + lane;
-          if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; }
-          else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
-          else over = true;
-        }
-#pragma unroll
-      for (int j = 0; j < kGroup; ++j) { cb[j] = nb[j]; cc[j] = nc[j]; }
-      K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
-    }
-  } else {
-  ScanRec c[kGroup], nx[kGroup];
-#pragma unroll
-  for (int j = 0; j < kGroup; ++j) c[j] = load_scan_rec(list_addr, j * kWave + lane);
   for (int g = 0; g < kGroups; ++g) {
+    if (g > 0 && !(readlane_f64(cb[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
     double ap[kGroup];
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) ap[j] = (c[j].te * c[j].cf) * size_factor;
-    if (g > 0 && !(readlane_f64(ap[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
-    double fl[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) fl[j] = field_load(A + c[j].cell);
+    for (int j = 0; j < kGroup; ++j) ap[j] = field_at(cc[j]);
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) {
       const int ch = (g + 1) * kGroup + j;
-      nx[j].te = 0.0; nx[j].cf = 1.0; nx[j].cell = 0;
-      if (ch < kChunks) nx[j] = load_scan_rec(list_addr, ch * kWave + lane);
+      nb[j] = 0.0; nc[j] = 0;
+      if (ch < kChunks) { nb[j] = pb_at(ch * kWave + lane); nc[j] = pc_at(ch * kWave + lane); }
     }
     double local = 0.0;
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) { ap[j] = ap[j] * fl[j]; local = dmax(local, ap[j]); }
+    for (int j = 0; j < kGroup; ++j) { ap[j] = cb[j] * ap[j]; local = dmax(local, ap[j]); }
     M = dmax(M, wave_max_f64(local));
     const double thr_now = M * kKeep;
 #pragma unroll
     for (int j = 0; j < kGroup; ++j)
       if (ap[j] >= thr_now && ap[j] > 0.0) {
         const int rank = (g * kGroup + j) * kWave + lane;
-        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1te = c[j].te; q1cf = c[j].cf; q1cell = c[j].cell; }
+        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1cell = cc[j]; }
         else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
         else over = true;
       }
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) c[j] = nx[j];
+    for (int j = 0; j < kGroup; ++j) { cb[j] = nb[j]; cc[j] = nc[j]; }
     K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
-  }
   }
   if (!(M >= 1e-250)) return kSearchFallback;      // (nothing placeable, or subnormal territory: the exact scan decides)
 #ifdef EG_STAMPS
@@ -1339,8 +1292,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
     ncand = n1 + __popcll(m2);
   } else {
     for (int k = 0; k < K; ++k) {
-      const PsRec r = load_rec(list_addr, k * kWave + lane);
-      const double approx = ((r.te * r.cf) * size_factor) * field_load(A + r.cell);
+      const double approx = pb_at(k * kWave + lane) * field_at(pc_at(k * kWave + lane));
       const unsigned long long m = __ballot(approx >= thr && approx > 0.0);
       if (m != 0ull) {
         const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
@@ -1357,14 +1309,10 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   const unsigned long long ts2 = __builtin_readcyclecounter();
 #endif
   ChunkBest b; b.score = 0.0; b.m03 = 0.0; b.cell = kCells;
-  if (ncand == 1 && solo >= 0) {      // the usual case: one candidate, its record still in the lane that found it
-    double te1, cf1; int cell1;
-    if constexpr (kLatency) { te1 = readlane_f64(q1te, solo); cf1 = readlane_f64(q1cf, solo); cell1 = __builtin_amdgcn_readlane(q1cell, solo); }
-    else { const PsRec e1 = load_rec(list_addr, __builtin_amdgcn_readlane(q1r, solo)); te1 = e1.te; cf1 = e1.cf; cell1 = (int)e1.cell; b.m03 = e1.m03; }
-    // (its m03 is requested before the product: it lands under it)
-    if constexpr (kLatency) b.m03 = *(GlobalF64c)(list_addr + (unsigned long long)(unsigned)__builtin_amdgcn_readlane(q1r, solo) * sizeof(PsRec) + 16ull);
-    b.score = (exact_product_chain<kLatency>(rc, tbl, ngen_s, te1, cell1, lane, tail_cells) * cf1) * size_factor;
-    b.cell = cell1;
+  if (ncand == 1 && solo >= 0) {      // the usual case: ONE candidate.  It is the arg-max — the arg-max is among the candidates — and nothing
+                                      // but its cell is asked for: its exact score (the reference's product over the whole list) need not be
+                                      // formed at all.  (It is positive: within 2^-42 of an approximate score of at least 1e-250.)
+    b.cell = __builtin_amdgcn_readlane(q1cell, solo); b.score = 1.0;
   } else if (ncand <= 4 || ngen_s > kLdsGens) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
                                                      // (chunk_product below walks the on-chip window only)
     for (int k = 0; k < ncand; ++k) {
@@ -2020,7 +1968,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             const unsigned long long th1 = __builtin_readcyclecounter();
             stamps[9] += th1 - th0;
 #endif
-            if (hr >= 0) { cell = hr & 0xFFFF; ep.chunks += hr >> 16; m03v = sm.hres[1].m03; placed = true; between(); }
+            if (hr >= 0) { cell = hr & 0xFFFF; ep.chunks += hr >> 16; m03v = T.m03()[cell]; placed = true; between(); }
 #ifdef EG_STAMPS
             stamps[10] += __builtin_readcyclecounter() - th1;
 #endif
