@@ -1336,9 +1336,9 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   wave_sync();
   if (lane == 0) sm.hres[1].m03 = b.m03;
   wave_sync();
-  // requested, in units of 2 KB (= a chunk of 64 records): the K chunks scanned and the winner's chunk (a second pass re-reads
-  // the first pass's records) and K x 64 field entries of 8 B (the field update that follows bills itself)
-  return b.cell | ((K + 1 + (K + 3) / 4) << 16);
+  // requested, in units of 2 KB: K chunks of the compact list (64 x 12 B each), K x 64 field entries of 8 B, and — only when several
+  // candidates tie — their full records (the field update that follows bills itself)
+  return b.cell | (((3 * K + 7) / 8 + (K + 3) / 4 + (ncand > 1 ? 1 : 0)) << 16);
 }
 
 // The exact scan for a list that has outgrown the on-chip window (long-replay variant; reached when the field path cannot
