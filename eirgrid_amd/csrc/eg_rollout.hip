@@ -1146,9 +1146,10 @@ template <bool kLatency>
 __device__ __noinline__ void heavy_build_class(unsigned long long class_addr, unsigned long long tail_cells, int lane, int rc, int table, int reach, int ngen) {
   const GlobalF64 f = (GlobalF64)class_addr;
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
-  // blocks per pass over the generator list: all of them with registers to spare (small-batch kernel); three passes of fourteen on
-  // the throughput kernel's 72 registers — it happens six times an episode at most
-  constexpr int kPer = kLatency ? kChunks : 14;
+  // blocks per pass over the generator list: all of them with registers to spare (small-batch kernel); six passes of seven on the
+  // throughput kernel's 72 registers (fourteen per pass spilled 17 of them: with seven the long-replay kernel needs no scratch memory
+  // at all) — it happens six times an episode at most
+  constexpr int kPer = kLatency ? kChunks : 7;
   const int cap = factor_cap<kLatency>(table);
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a field update of the other classes may still be in flight)
@@ -1223,10 +1224,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last field update's stores are in L2 before anything gathers
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
   constexpr int kChunks = (kCells + kWave - 1) / kWave;      // 41: the list holds exactly kChunks * 64 records
-#ifndef EG_SCAN_GROUP
-#define EG_SCAN_GROUP 4
-#endif
-  constexpr int kGroup = EG_SCAN_GROUP, kGroups = (kChunks + kGroup - 1) / kGroup;
+  constexpr int kGroup = 4, kGroups = (kChunks + kGroup - 1) / kGroup;
   constexpr double kKeep = 1.0 - 0x1p-30;
   // 1. largest approximate score M, scanning in descending order of the unpenalised score, four chunks per memory round
   //    trip (the records of the next group are requested while this group's field entries are on their way).  A lane
