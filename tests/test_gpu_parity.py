@@ -552,6 +552,54 @@ def test_heavy_episodes_match_the_oracle(world):
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
 
 
+@pytest.mark.gpu
+def test_heavy_searches_with_tied_candidates_match_the_oracle():
+    """A world that is symmetric about both centre lines and the diagonals (one settlement in the middle of the map, no plant, no
+    coast): every placement score is shared by up to eight cells, bit for bit.  A long replay's search then finds several
+    candidates within 2^-30 of the largest approximate score — the single-candidate rule (its cell is the answer, no exact
+    evaluation) does not apply —, evaluates them exactly and must take the lowest cell of the tied maxima, as the reference's
+    first-strictly-greater scan does (metal_location_search.rs:168-171).  Against the tabled oracle, and against an engine
+    without the field pool (every search the exact scan)."""
+    w = World(np.array([25000.0]), np.array([25000.0]), np.array([400000], dtype=np.uint32), np.zeros(0), np.zeros(0),
+              np.zeros(0, np.int32), np.zeros(0), np.zeros(0), np.zeros(0))
+    tb = O.OracleTables(HostTables(w), 0)
+    rng = np.random.default_rng(5)
+    pol = ActionWeights()
+    types = [0, 4, 12, 7, 8]
+    run = [[int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(9)] for _ in range(26)]
+    nr = np.array([len(l) for l in run], np.int32)
+    pol.apply_episode([-5e4, 0.7, 4e10, 1.0], nr, np.array([a for l in run for a in l], np.uint8), np.zeros(26, np.int32), np.zeros(0, np.uint8))
+    n = 24
+    mask = np.ones(n, np.uint8)
+    results = {}
+    for mode, slots in (("0", None), ("all", None), ("0", "0")):
+        os.environ["EIRGRID_HELPER_WAVES"] = mode
+        if slots is not None:
+            os.environ["EIRGRID_HEAVY_SLOTS"] = slots
+        try:
+            eng = Engine(w, device=0)
+        finally:
+            del os.environ["EIRGRID_HELPER_WAVES"]
+            os.environ.pop("EIRGRID_HEAVY_SLOTS", None)
+        try:
+            results[(mode, slots)] = eng.rollout_batch(pol, 77, n, replay_mask=mask)
+        finally:
+            eng.close()
+    a = results[("0", None)]
+    assert (a.status == 0).all() and a.n_gens.min() >= 200
+    for key, b in results.items():
+        for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "run_log", "def_log", "act_log",
+                     "gen_cell", "gen_pack", "off_pack"):
+            assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (key, name)
+    for e in (0, 7, 23):
+        st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 77 + e, replay=True)
+        assert_episode_equal(a, e, ref, "symmetric world, replay")
+    # the ties are real: mirror cells (i, j) / (50 - i, j) / (j, i) ... carry the same unpenalised score, so the early placements
+    # of an episode take the lowest cell of a tied set — cells in the first half of the grid
+    first = a.gen_cell[0, :4].astype(int)
+    assert ((first // 51) <= 25).all(), first
+
+
 def test_field_pool_is_only_held_once_the_best_list_is_long(world):
     """The penalty-field pool of long replay episodes (126 KB per replay episode of a launch) is allocated when the best list is
     known to be longer than 96 actions, not with the first replay episode: replays of config 1's episode never ask for a slot."""
