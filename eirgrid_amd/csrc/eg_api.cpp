@@ -401,6 +401,26 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       while (i < nbox && i < 1024 && int(box[i] >> 19) < k) ++i;
       box[1024 + k] = uint32_t(i);
     }
+    // ... and packed for every subset of classes, in the throughput kernel's form (tab::hv_lists): the long-replay variant reads its
+    // subset's list from here (a few KB that every long replay of a CU shares) instead of keeping 4 KB of LDS for a copy of its own
+    if (rc == EG_OK && nbox <= 1024) {
+      const int32_t* meta = reinterpret_cast<const int32_t*>(blob.data() + tab::dr_meta);
+      uint32_t* lists = reinterpret_cast<uint32_t*>(blob.data() + tab::hv_lists);
+      int32_t* quads = reinterpret_cast<int32_t*>(blob.data() + tab::hv_quads);
+      auto place = [&](uint32_t en) -> uint32_t {
+        const int k = int(en >> 19), q = int((en >> 10) & 511u);
+        return (en & ~(511u << 10)) | (uint32_t(meta[k] + std::min(q, meta[8 + k])) << 10);
+      };
+      for (int mask = 0; mask < 64; ++mask) {
+        uint32_t* l = lists + size_t(mask) * 1024;
+        int n = 0;
+        for (int k = 0; k < kRadiusClasses; ++k)
+          if ((mask >> k) & 1) for (uint32_t i = box[1024 + k]; i < box[1024 + k + 1]; ++i) l[n++] = place(box[i]);
+        const int padded = (n + 255) & ~255;
+        for (int i = n; i < 1024; ++i) l[i] = place(145u << 10);
+        quads[mask] = padded / 256;
+      }
+    }
   }
   if (rc == EG_OK) {
     void* p = nullptr;

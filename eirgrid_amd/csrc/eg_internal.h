@@ -109,7 +109,12 @@ constexpr size_t dr_compact = a16(dr_meta + 4 * 16);
 // offsets of the tables the lean kernels read stay small.
 constexpr size_t pbase = a16(dr_compact + 8 * size_t(kDrCompact));                     // f64 [26][kMaxVariants][kPsStride]
 constexpr size_t pcell = a16(pbase + 8 * size_t(kYears) * kMaxVariants * kPsStride);     // u32 [26][kMaxVariants][kPsStride]
-constexpr size_t total = pcell + 4 * size_t(kYears) * kMaxVariants * kPsStride;
+// the field update's entry list (hv_box) packed for every subset of radius classes an episode may keep a field for, as the throughput
+// kernel reads it (eg_rollout.hip heavy_add_body: the entry's place in the compact factor table instead of its squared distance),
+// padded to a multiple of four entries per lane; hv_quads = that multiple.  (The small-batch kernel packs its own list into LDS.)
+constexpr size_t hv_lists = a16(pcell + 4 * size_t(kYears) * kMaxVariants * kPsStride);     // u32 [64][1024]
+constexpr size_t hv_quads = a16(hv_lists + 4 * size_t(64) * 1024);                          // i32 [64]
+constexpr size_t total = hv_quads + 4 * 64;
 }  // namespace tab
 
 struct DevTables {
@@ -129,7 +134,7 @@ struct DevTables {
   EG_TAB(reach, int32_t)
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
-  EG_TAB(ps, PsRec) EG_TAB(pbase, double) EG_TAB(pcell, uint32_t) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
+  EG_TAB(ps, PsRec) EG_TAB(pbase, double) EG_TAB(pcell, uint32_t) EG_TAB(hv_lists, uint32_t) EG_TAB(hv_quads, int32_t) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
 #undef EG_TAB
 };
 

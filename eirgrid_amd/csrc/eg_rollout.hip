@@ -1079,6 +1079,12 @@ struct __align__(16) SmemHeavy {
   uint32_t box[kBoxEntries];               // di + 16 | (dj + 16) << 5 | q << 10 (9 bits; throughput kernels: place in sm.dr) | class << 19
 };
 __shared__ SmemHeavy sh;
+// Throughput kernel: a copy of the first eight entries per lane only — the list of up to three or four radius classes, the usual case,
+// 2 KB: with it the variant stays at nine LDS granules, which still lets sixteen waves share a CU beside the lean grid (eleven granules
+// did not) —; entries beyond come from tab::hv_lists itself.
+constexpr int kBoxLds = 8 * kWave;
+struct __align__(16) SmemHeavyTp { uint32_t box[kBoxLds]; };
+__shared__ SmemHeavyTp sh2;
 typedef const uint32_t __attribute__((address_space(1)))* GlobalU32c;
 // sh.box = the entries of the radius classes in `classes` (the host's list is sorted by class; its words 1024..1030 are where
 // each class starts), padded to a multiple of four per lane; returns that multiple (1..4)
@@ -1109,8 +1115,11 @@ __device__ __noinline__ int heavy_pack_list(unsigned long long box_addr, unsigne
 // Throughput kernel: inlined.  A function that is not waits for its stores to be acknowledged before it returns (s_waitcnt vmcnt(0) ahead of
 // s_setpc), and waits on entry for whatever its caller had in flight: as a call, the update cost the episode its own loads, then its
 // stores' round trip, and before that the cost terms the caller had just requested — three exposed latencies where one is needed.
+// `list_addr` (throughput kernel): the entry list of the episode's classes, packed by the host for every subset of classes
+// (tab::hv_lists); its first eight entries per lane are in LDS (sh2.box, copied when a class joins).  The small-batch kernel, with LDS
+// to spare, packs its own list (sh.box).
 template <bool kLatency, int kPerLane>
-__device__ __forceinline__ void heavy_add_body(unsigned long long field_addr, int lane, int cell, int first) {
+__device__ __forceinline__ void heavy_add_body(unsigned long long field_addr, unsigned long long list_addr, int lane, int cell, int first) {
 #ifdef EG_STAMPS
   const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
@@ -1118,7 +1127,11 @@ __device__ __forceinline__ void heavy_add_body(unsigned long long field_addr, in
   const GlobalF64 base = (GlobalF64)field_addr;
   double val[kPerLane], fac[kPerLane]; int off[kPerLane]; uint32_t ens[kPerLane];
 #pragma unroll
-  for (int k = 0; k < kPerLane; ++k) ens[k] = sh.box[(first + k) * kWave + lane];
+  for (int k = 0; k < kPerLane; ++k) {
+    if constexpr (kLatency) ens[k] = sh.box[(first + k) * kWave + lane];
+    else if ((first + k) * kWave < kBoxLds) ens[k] = sh2.box[(first + k) * kWave + lane];      // (`first` is a constant at every call site)
+    else ens[k] = ((GlobalU32c)list_addr)[(first + k) * kWave + lane];
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (all list entries in one LDS round trip, not one after the other)
 #pragma unroll
   for (int k = 0; k < kPerLane; ++k) {
@@ -1137,7 +1150,7 @@ __device__ __forceinline__ void heavy_add_body(unsigned long long field_addr, in
 #endif
 }
 template <bool kLatency, int kPerLane>
-__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int first) { heavy_add_body<kLatency, kPerLane>(field_addr, lane, cell, first); }
+__device__ __noinline__ void heavy_add(unsigned long long field_addr, int lane, int cell, int first) { heavy_add_body<kLatency, kPerLane>(field_addr, 0ull, lane, cell, first); }
 // A class joins: its field = for every cell the product of the factors of the generators placed so far (any order: the
 // field only serves a bound).  The field of the 41 blocks of 64 cells sits in registers while the generators pass by; a
 // generator only touches the blocks whose rows come within `reach` of its own row (a scalar test per block).
@@ -1954,7 +1967,14 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
             if (!((ep.heavy_classes >> hrc) & 1)) {      // the first search of this radius class: its field joins
               heavy_build_class<(kHelpers > 0)>(class_addr, tail.gen_cell, lane, hrc, throughput_table(info), (info >> 8) & 15, ep.ngen);
               ep.heavy_classes |= 1 << hrc;
-              ep.heavy_quads = heavy_pack_list<(kHelpers > 0)>((unsigned long long)(T.base + tab::hv_box), (unsigned long long)(T.base + tab::dr_meta), lane, ep.heavy_classes);
+              if constexpr (kHelpers > 0) ep.heavy_quads = heavy_pack_list<true>((unsigned long long)(T.base + tab::hv_box), (unsigned long long)(T.base + tab::dr_meta), lane, ep.heavy_classes);
+              else {      // the host packed the list of every subset of classes: this episode's is copied (its first eight entries per lane)
+                ep.heavy_quads = __builtin_amdgcn_readfirstlane(T.hv_quads()[ep.heavy_classes]);
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < kBoxLds / kWave; ++k) sh2.box[k * kWave + lane] = T.hv_lists()[ep.heavy_classes * 1024 + k * kWave + lane];
+                wave_sync();
+              }
             }
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
@@ -2002,10 +2022,11 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
               default: heavy_add<true, 16>(field_addr, lane, cell, 0); break;
             }
           } else {
-            if (ep.heavy_quads == 1) heavy_add_body<false, 4>(field_addr, lane, cell, 0);
-            else heavy_add_body<false, 8>(field_addr, lane, cell, 0);
-            if (ep.heavy_quads == 3) heavy_add_body<false, 4>(field_addr, lane, cell, 8);
-            else if (ep.heavy_quads >= 4) heavy_add_body<false, 8>(field_addr, lane, cell, 8);
+            const unsigned long long hv_list = (unsigned long long)(T.hv_lists() + ep.heavy_classes * 1024);
+            if (ep.heavy_quads == 1) heavy_add_body<false, 4>(field_addr, hv_list, lane, cell, 0);
+            else heavy_add_body<false, 8>(field_addr, hv_list, lane, cell, 0);
+            if (ep.heavy_quads == 3) heavy_add_body<false, 4>(field_addr, hv_list, lane, cell, 8);
+            else if (ep.heavy_quads >= 4) heavy_add_body<false, 8>(field_addr, hv_list, lane, cell, 8);
           }
         }
         if constexpr (kPark) {
@@ -2208,7 +2229,6 @@ __global__ void __launch_bounds__(kWave, 7) k_heavy_register_budget(unsigned lon
   int r = place_heavy<false>(a, b, c, a + b, b + c, d, lane, i, i, i);
   r += place_exact_long<false>(a, c, d, lane, i, i, i);
   heavy_build_class<false>(a, c, lane, i, i, i, i);
-  r += heavy_pack_list<false>(a, b, lane, i);
   out[lane] = r;
 }
 #endif
