@@ -623,19 +623,46 @@ int32_t eg_sync(eg_ctx* c) {
 }
 
 namespace {
-// one strided copy per requested field: episode records are rec::stride bytes apart on the device
+// One strided copy per requested field: episode records are rec::stride bytes apart on the device.  The lists of a record have the
+// oracle's capacity (4 096 entries: 41.6 KB per episode), an episode fills a fraction of it (a sampled one about 1 KB): the counts
+// come first, and every list is then copied only as wide as the longest of the batch needs — the caller's rows keep their full
+// pitch, what lies behind an episode's entries is left as the caller passed it.  (EIRGRID_FETCH_FULL=1: whole rows, for the
+// diagnostic builds that park their cycle stamps at the end of act_log.)
 int fetch_records(const uint8_t* d_base, size_t N, eg_episode_out* o) {
-#define EG_GET(field, count, type) \
-  if (o->field) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), d_base + rec::field, rec::stride, (count) * sizeof(type), N, hipMemcpyDeviceToHost))
+#define EG_GET_W(field, count, type, used) \
+  if (o->field && (used) > 0) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), d_base + rec::field, rec::stride, (used) * sizeof(type), N, hipMemcpyDeviceToHost))
+#define EG_GET(field, count, type) EG_GET_W(field, count, type, count)
   EG_GET(metrics, 4, double); EG_GET(yearly, EG_YEARS * EG_YEARLY_FIELDS, double); EG_GET(status, 1, int32_t);
-  EG_GET(n_run, EG_YEARS, int32_t); EG_GET(n_def, EG_YEARS, int32_t); EG_GET(n_act, EG_YEARS, int32_t);
-  EG_GET(run_log, EG_RUN_CAP, uint8_t); EG_GET(def_log, EG_DEF_CAP, uint8_t); EG_GET(act_log, EG_ACT_CAP, uint8_t);
-  EG_GET(n_gens, 1, int32_t); EG_GET(gen_cell, EG_MAX_GENS, uint16_t); EG_GET(gen_pack, EG_MAX_GENS, uint16_t);
-  EG_GET(n_offsets, 1, int32_t); EG_GET(off_pack, EG_MAX_OFFSETS, uint16_t);
+  EG_GET(n_gens, 1, int32_t); EG_GET(n_offsets, 1, int32_t);
   EG_GET(bytes_moved, 1, double);
   EG_GET(n_draws, 1, uint64_t);
   EG_GET(n_chunks, 1, uint32_t);
+  static const bool full = [] { const char* f = std::getenv("EIRGRID_FETCH_FULL"); return f && f[0] == '1'; }();
+  size_t run = EG_RUN_CAP, def = EG_DEF_CAP, act = EG_ACT_CAP, gens = EG_MAX_GENS, offs = EG_MAX_OFFSETS;
+  const bool lists = o->run_log || o->def_log || o->act_log || o->gen_cell || o->gen_pack || o->off_pack;
+  std::vector<int32_t> cnt;      // n_run | n_def | n_act [26] each, n_gens, n_offsets: the header of a record, contiguous from rec::status on
+  if (lists && !full) {
+    constexpr size_t kHead = rec::yearly - rec::status;      // status, n_gens, n_offsets, n_chunks, n_run, n_def, n_act
+    static_assert(rec::n_gens == rec::status + 4 && rec::n_offsets == rec::status + 8 && rec::n_run == rec::status + 16, "record header");
+    cnt.resize(N * (kHead / 4));
+    EG_HIP(hipMemcpy2D(cnt.data(), kHead, d_base + rec::status, rec::stride, kHead, N, hipMemcpyDeviceToHost));
+    run = def = act = gens = offs = 0;
+    for (size_t e = 0; e < N; ++e) {
+      const int32_t* h = cnt.data() + e * (kHead / 4);
+      size_t r = 0, d = 0, a = 0;
+      for (int y = 0; y < EG_YEARS; ++y) { r += size_t(std::max(h[4 + y], 0)); d += size_t(std::max(h[4 + EG_YEARS + y], 0)); a += size_t(std::max(h[4 + 2 * EG_YEARS + y], 0)); }
+      run = std::max(run, r); def = std::max(def, d); act = std::max(act, a);
+      gens = std::max(gens, size_t(std::max(h[1], 0))); offs = std::max(offs, size_t(std::max(h[2], 0)));
+    }
+    run = std::min(run, size_t(EG_RUN_CAP)); def = std::min(def, size_t(EG_DEF_CAP)); act = std::min(act, size_t(EG_ACT_CAP));
+    gens = std::min(gens, size_t(EG_MAX_GENS)); offs = std::min(offs, size_t(EG_MAX_OFFSETS));
+  }
+  EG_GET(n_run, EG_YEARS, int32_t); EG_GET(n_def, EG_YEARS, int32_t); EG_GET(n_act, EG_YEARS, int32_t);
+  EG_GET_W(run_log, EG_RUN_CAP, uint8_t, run); EG_GET_W(def_log, EG_DEF_CAP, uint8_t, def); EG_GET_W(act_log, EG_ACT_CAP, uint8_t, act);
+  EG_GET_W(gen_cell, EG_MAX_GENS, uint16_t, gens); EG_GET_W(gen_pack, EG_MAX_GENS, uint16_t, gens);
+  EG_GET_W(off_pack, EG_MAX_OFFSETS, uint16_t, offs);
 #undef EG_GET
+#undef EG_GET_W
   return EG_OK;
 }
 }  // namespace

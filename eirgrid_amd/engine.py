@@ -297,9 +297,12 @@ class Engine:
 
     def rollout_batch(self, weights: ActionWeights, seed: int, n_episodes: int, first_episode_index: int = 0,
                       replay_mask=None, enable_energy_sales=True, enable_construction_delays=False,
-                      write_yearly=True) -> BatchResult:
-        """Batched `run_iteration` (core/iteration.rs:10-20): episodes first..first+n against one weights snapshot."""
-        res = BatchResult.alloc(n_episodes)
+                      write_yearly=True, out: "BatchResult" = None) -> BatchResult:
+        """Batched `run_iteration` (core/iteration.rs:10-20): episodes first..first+n against one weights snapshot.
+        `out`: a BatchResult of the same size to fill again (a caller in a loop keeps its buffers; list entries behind an episode's
+        counts keep whatever they held)."""
+        res = out if out is not None else BatchResult.alloc(n_episodes)
+        assert res.status.shape == (n_episodes,)
         snap = weights.snapshot()
         opts = self._opts(enable_energy_sales, enable_construction_delays, write_yearly)
         mask = None

@@ -161,7 +161,9 @@ void eg_destroy(eg_ctx *);
 /* Run episodes [first_episode_index, first_episode_index + n) against one snapshot.  Episode e draws from
  * StdRng::seed_from_u64(seed + e) (the reference gives every episode the same stream under --seed,
  * core/simulation.rs:50-53; e = 0 reproduces that).  replay_mask[i] != 0 runs episode i with
- * replay_best_strategy = true (core/multi_simulation.rs:461-465).  Results are copied into `out`. */
+ * replay_best_strategy = true (core/multi_simulation.rs:461-465).  Results are copied into `out`: the scalar fields and the per-year
+ * counts of every episode, and of each list (run_log, def_log, act_log, gen_cell, gen_pack, off_pack) the entries the counts
+ * announce — a row's bytes behind the longest list of the batch are not written (they keep what the caller's buffer held). */
 int32_t eg_rollout_batch(eg_ctx *, const eg_policy_snapshot *, const eg_opts *, uint64_t seed,
                          uint64_t first_episode_index, uint32_t n_episodes, const uint8_t *replay_mask,
                          eg_episode_out *out);

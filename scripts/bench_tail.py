@@ -1,6 +1,7 @@
 """Diagnostic (stamps build): per-step kernel time vs the distribution of episode cycle counts along the bench trajectory.
    EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/bench_tail.py [B] [steps]"""
 import os, sys
+os.environ["EIRGRID_FETCH_FULL"] = "1"      # (the stamps sit at the end of act_log: whole rows, please)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from eirgrid_amd import synthetic_world

@@ -1,6 +1,7 @@
 """Diagnostic: where does a heavy (replay) episode spend its cycles?  -DEG_STAMPS build (make -C eirgrid_amd/csrc stamps):
    EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/heavy_stamps.py [per_year]"""
 import os, sys
+os.environ["EIRGRID_FETCH_FULL"] = "1"      # (the stamps sit at the end of act_log: whole rows, please)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from eirgrid_amd import synthetic_world

@@ -2,6 +2,7 @@
    EIRGRID_LIB=eirgrid_amd/libeirgrid_hip_stamps.so python scripts/stamps.py
 Every cycle of an episode is charged to exactly one slot.  Shares only; never quote this build's run time."""
 import os, sys
+os.environ["EIRGRID_FETCH_FULL"] = "1"      # (the stamps sit at the end of act_log: whole rows, please)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from eirgrid_amd import synthetic_world

@@ -552,6 +552,31 @@ def test_heavy_episodes_match_the_oracle(world):
     assert kernel_ms[("0", None)] < 0.5 * kernel_ms[("0", "0")] and kernel_ms[("all", None)] < 0.5 * kernel_ms[("all", "0")]
 
 
+def test_fetch_copies_the_lists_as_wide_as_the_batch_needs(engine):
+    """eg_rollout_batch copies the counts and, of every list, only the entries the longest list of the batch announces
+    (include/eirgrid_hip.h): into a caller's buffer full of a marker byte the entries within an episode's counts are the episode's,
+    and nothing behind the batch's longest list is touched."""
+    from eirgrid_amd.engine import BatchResult
+    n = 48
+    ref = engine.rollout_batch(ActionWeights(), 4242, n)
+    out = BatchResult.alloc(n)
+    for name in ("run_log", "def_log", "act_log", "gen_cell", "gen_pack", "off_pack"):
+        getattr(out, name).view(np.uint8)[:] = 0xAB
+    res = engine.rollout_batch(ActionWeights(), 4242, n, out=out)
+    assert res is out and (res.status == 0).all()
+    for name in ("metrics", "yearly", "status", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws"):
+        assert getattr(res, name).tobytes() == getattr(ref, name).tobytes(), name
+    widths = {"run_log": res.n_run.sum(axis=1), "def_log": res.n_def.sum(axis=1), "act_log": res.n_act.sum(axis=1),
+              "gen_cell": res.n_gens, "gen_pack": res.n_gens, "off_pack": res.n_offsets}
+    for name, used in widths.items():
+        a, b = getattr(res, name), getattr(ref, name)
+        w = int(used.max())
+        assert 0 < w < a.shape[1] or name == "off_pack"
+        for e in range(n):
+            assert (a[e, :used[e]] == b[e, :used[e]]).all(), (name, e)
+        assert (a[:, w:].view(np.uint8) == 0xAB).all(), f"{name}: written behind the batch's longest list"
+
+
 @pytest.mark.gpu
 def test_heavy_searches_with_tied_candidates_match_the_oracle():
     """A world that is symmetric about both centre lines and the diagonals (one settlement in the middle of the map, no plant, no
