@@ -8,7 +8,8 @@
 // are folded in the reference's list order and every transcendental is a host-built table (eg_tables.cpp), so device
 // code is + - * / compare only and reproduces the CPU oracle bit for bit; chains that only feed a decision (the samplers'
 // sum-and-walk) are replaced by a parallel form where that provably gives the same decision (weighted_pick).
-// Build: -ffp-contract=off (no FMA).  Further kernels: k_apply_update (the batch update, on the device),
+// Build: -ffp-contract=off (no FMA); compiled twice — the throughput kernels as an object of their own, see EG_TU_THROUGHPUT
+// below and csrc/Makefile.  Further kernels: k_apply_update (the batch update, on the device),
 // k_stalled_tables, k_pick_best, k_update_stats, k_place.
 // Two measured facts shape the code: (1) in the small-batch kernel a lone wave issues one instruction per turn of its
 // SIMD, whatever the instruction — the hot loops are written for instruction count, scalar and wait instructions
@@ -1641,8 +1642,8 @@ __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b)
   return m.off + (q / p1) * m.period + 1u + q % p1;
 }
 
-// (the heavy variant trades occupancy for registers: two waves per SIMD, 256 VGPRs — its grid is the few long episodes,
-//  which are bound by their own serial latency, and the field code inlines without spilling)
+// (the heavy-capable variant: four waves per SIMD in the throughput kernel — 128 VGPRs, the field code held to 72 by
+//  k_heavy_register_budget, the year's aggregates parked in LDS around its calls —, two in the small-batch kernel — 256 VGPRs)
 // kKind: kLean = sampled episodes only (no replay code at all); kReplayShort / kReplayLong = the episodes that replay the best
 // strategy, on the lean kernel's budget while the replayed list is short and on the heavy-capable variant once it is long.
 // Both are launched over the replay episodes of a batch and the one whose turn it is not returns at once: how long the list
