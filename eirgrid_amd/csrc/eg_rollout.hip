@@ -1241,12 +1241,14 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   constexpr int kGroup = 4, kGroups = (kChunks + kGroup - 1) / kGroup;
   constexpr double kKeep = 1.0 - 0x1p-30;
   // 1. largest approximate score M, scanning in descending order of the unpenalised score, four chunks per memory round
-  //    trip (the records of the next group are requested while this group's field entries are on their way).  A lane
-  //    remembers up to two of its entries that were within 2^-30 of the running maximum when it saw them — M only grows,
-  //    so whatever is within 2^-30 of the final M was so then.  A third one (ties en masse) sends the search to pass 2.
+  //    trip (the records of the next group are requested while this group's field entries are on their way).  Branch-free per
+  //    candidate: a lane keeps its largest approximate score, with the chunk it was seen in written into the value's six lowest
+  //    bits (2^-46 relative: far inside the 2^-30 the candidates are kept by; one v_max then keeps value and place) and that
+  //    candidate's cell, and its second largest as a value only.  Between rounds only the high words of the lanes' maxima are
+  //    reduced — a lower bound of M, within 2^-20: the stop rule scans a little further at most —, the full maximum once at the end.
+  //    Should a lane's second largest too end up within 2^-30 of M (ties en masse), pass 2 collects the candidates.
   double M = 0.0; int K = 0;
-  double q1v = 0.0, q2v = 0.0; int q1r = -1, q2r = -1; bool over = false;
-  int q1cell = 0;      // the cell of q1 stays with it: the usual single candidate needs nothing else
+  double lm = 0.0, l2 = 0.0; int lcell = 0;
   // (the addresses are the same in every lane: as scalar registers they leave every request a 32-bit lane offset — the 72 registers of
   //  this function have no room for an address pair per request)
   auto uniform_u64 = [](unsigned long long a) { return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a); };
@@ -1269,39 +1271,33 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
       nb[j] = 0.0; nc[j] = 0;
       if (ch < kChunks) { nb[j] = pb_at(ch * kWave + lane); nc[j] = pc_at(ch * kWave + lane); }
     }
-    double local = 0.0;
 #pragma unroll
-    for (int j = 0; j < kGroup; ++j) { ap[j] = cb[j] * ap[j]; local = dmax(local, ap[j]); }
-    M = dmax(M, wave_max_f64(local));
-    const double thr_now = M * kKeep;
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j)
-      if (ap[j] >= thr_now && ap[j] > 0.0) {
-        const int rank = (g * kGroup + j) * kWave + lane;
-        if (q1r < 0 || q1v < thr_now) { q1v = ap[j]; q1r = rank; q1cell = cc[j]; }
-        else if (q2r < 0 || q2v < thr_now) { q2v = ap[j]; q2r = rank; }
-        else over = true;
-      }
+    for (int j = 0; j < kGroup; ++j) {
+      const double v = cb[j] * ap[j];
+      const double key = __hiloint2double(__double2hiint(v), (__double2loint(v) & ~63) | (g * kGroup + j));
+      const bool larger = key > lm;
+      l2 = dmax(l2, dmin(lm, key));
+      lm = dmax(lm, key);
+      lcell = larger ? cc[j] : lcell;
+    }
+    M = __hiloint2double((int)wave_max_u32((unsigned)__double2hiint(lm)), 0);      // (scores are not negative: ordered like their bit patterns)
 #pragma unroll
     for (int j = 0; j < kGroup; ++j) { cb[j] = nb[j]; cc[j] = nc[j]; }
     K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
   }
+  M = wave_max_f64(lm);
   if (!(M >= 1e-250)) return kSearchFallback;      // (nothing placeable, or subnormal territory: the exact scan decides)
 #ifdef EG_STAMPS
   const unsigned long long ts1 = __builtin_readcyclecounter();
 #endif
-  // 2. the candidates: everything within 2^-30 of M
+  // 2. the candidates: everything within 2^-30 of M (as ranks in the sorted list, in sm.gstage[1])
   const double thr = M * kKeep;
-  int ncand = 0, solo = -1;      // solo: the lane whose q1 is the only candidate
-  if (__ballot(over) == 0ull) {
-    const unsigned long long m1 = __ballot(q1r >= 0 && q1v >= thr), m2 = __ballot(q2r >= 0 && q2v >= thr);
-    if (m2 == 0ull && __popcll(m1) == 1) solo = __ffsll((long long)m1) - 1;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int n1 = __popcll(m1);
-    if ((m1 >> lane) & 1ull) sm.gstage[1][__popcll(m1 & below)] = q1r;
-    const int p2 = n1 + __popcll(m2 & below);
-    if (((m2 >> lane) & 1ull) && p2 < kWave) sm.gstage[1][p2] = q2r;
-    ncand = n1 + __popcll(m2);
+  int ncand = 0, solo = -1;      // solo: the lane that holds the only candidate
+  if (__ballot(l2 >= thr) == 0ull) {      // (thr > 0) no lane has seen two: the candidates are the lanes' own maxima
+    const unsigned long long m1 = __ballot(lm >= thr);
+    ncand = __popcll(m1);
+    if (ncand == 1) solo = __ffsll((long long)m1) - 1;
+    if ((m1 >> lane) & 1ull) sm.gstage[1][__popcll(m1 & ((1ull << lane) - 1ull))] = (__double2loint(lm) & 63) * kWave + lane;
   } else {
     for (int k = 0; k < K; ++k) {
       const double approx = pb_at(k * kWave + lane) * field_at(pc_at(k * kWave + lane));
@@ -1324,7 +1320,7 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   if (ncand == 1 && solo >= 0) {      // the usual case: ONE candidate.  It is the arg-max — the arg-max is among the candidates — and nothing
                                       // but its cell is asked for: its exact score (the reference's product over the whole list) need not be
                                       // formed at all.  (It is positive: within 2^-42 of an approximate score of at least 1e-250.)
-    b.cell = __builtin_amdgcn_readlane(q1cell, solo); b.score = 1.0;
+    b.cell = __builtin_amdgcn_readlane(lcell, solo); b.score = 1.0;
   } else if (ncand <= 4 || ngen_s > kLdsGens) {      // one at a time, generator-parallel factors and the sequential product (exact_product_chain)
                                                      // (chunk_product below walks the on-chip window only)
     for (int k = 0; k < ncand; ++k) {
