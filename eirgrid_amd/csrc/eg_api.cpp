@@ -349,9 +349,9 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return base[a] > base[b]; });
         PsRec* list = ps + (size_t(y) * kMaxVariants + v) * kPsStride;
         for (int r = 0; r < kPsStride; ++r) { list[r].te = 0.0; list[r].cf = 1.0; list[r].m03 = 0.0; list[r].cell = 0; list[r].pad = 0; }
-        double* pb = reinterpret_cast<double*>(blob.data() + tab::pbase) + (size_t(y) * kMaxVariants + v) * kPsStride;
-        uint32_t* pc = reinterpret_cast<uint32_t*>(blob.data() + tab::pcell) + (size_t(y) * kMaxVariants + v) * kPsStride;
-        for (int r = 0; r < kPsStride; ++r) { pb[r] = r < kCells ? base[order[r]] : 0.0; pc[r] = r < kCells ? uint32_t(order[r]) : 0u; }
+        double* pb = reinterpret_cast<double*>(blob.data() + tab::pbase) + (size_t(y) * kMaxVariants + v) * kPcStride;
+        uint32_t* pc = reinterpret_cast<uint32_t*>(blob.data() + tab::pcell) + (size_t(y) * kMaxVariants + v) * kPcStride;
+        for (int r = 0; r < kPcStride; ++r) { pb[r] = r < kCells ? base[order[r]] : 0.0; pc[r] = r < kCells ? uint32_t(order[r]) : 0u; }
         for (int r = 0; r < kCells; ++r) {
           list[r].te = te[order[r]]; list[r].cf = marine ? H.coastf[order[r]] : 1.0; list[r].m03 = H.m03[order[r]]; list[r].cell = uint32_t(order[r]);
           list[r].pad = uint32_t(4 * (order[r] / kGrid)) | (uint32_t(4 * (order[r] % kGrid)) << 16);

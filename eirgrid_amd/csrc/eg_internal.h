@@ -22,6 +22,8 @@ constexpr int kDrCompact = 352;      // doubles of the compact factor table (the
 constexpr int kLdsGens = EG_ONCHIP_GENS;      // generators / offsets of an episode that the kernels keep in LDS; the long-replay variant goes on in the episode's record
 constexpr int kShortReplayMax = 96;   // actions in the best list up to which replay episodes stay on the exact scan (eg_rollout.hip, k_rollout kinds)
 constexpr int kMaxVariants = 12;  // distinct (radius class, marine) pairs over the 15 types (8 for the reference's types)
+constexpr int kPcStride = 48 * 64;  // entries per list of the compact form (tab::pbase / pcell): the 41 chunks, then zeros — the scan requests a round of four chunks
+                                    // ahead without asking whether the list has ended
 
 // Policy-independent tables, built once per world on the host (eg_tables.cpp) and mirrored in HBM.
 // Everything a kernel needs that involves sqrt / division by data / pow / exp lives here, so device code only
@@ -107,12 +109,12 @@ constexpr size_t dr_compact = a16(dr_meta + 4 * 16);
 // the sorted candidates once more as what the approximate scan of the long-replay variant reads of them (eg_rollout.hip place_heavy):
 // the unpenalised score (te * cf) * size_factor and the cell, three registers per chunk in flight instead of eight.  Last, so that the
 // offsets of the tables the lean kernels read stay small.
-constexpr size_t pbase = a16(dr_compact + 8 * size_t(kDrCompact));                     // f64 [26][kMaxVariants][kPsStride]
-constexpr size_t pcell = a16(pbase + 8 * size_t(kYears) * kMaxVariants * kPsStride);     // u32 [26][kMaxVariants][kPsStride]
+constexpr size_t pbase = a16(dr_compact + 8 * size_t(kDrCompact));                     // f64 [26][kMaxVariants][kPcStride]
+constexpr size_t pcell = a16(pbase + 8 * size_t(kYears) * kMaxVariants * kPcStride);     // u32 [26][kMaxVariants][kPcStride]
 // the field update's entry list (hv_box) packed for every subset of radius classes an episode may keep a field for, as the throughput
 // kernel reads it (eg_rollout.hip heavy_add_body: the entry's place in the compact factor table instead of its squared distance),
 // padded to a multiple of four entries per lane; hv_quads = that multiple.  (The small-batch kernel packs its own list into LDS.)
-constexpr size_t hv_lists = a16(pcell + 4 * size_t(kYears) * kMaxVariants * kPsStride);     // u32 [64][1024]
+constexpr size_t hv_lists = a16(pcell + 4 * size_t(kYears) * kMaxVariants * kPcStride);     // u32 [64][1024]
 constexpr size_t hv_quads = a16(hv_lists + 4 * size_t(64) * 1024);                          // i32 [64]
 constexpr size_t total = hv_quads + 4 * 64;
 }  // namespace tab

@@ -1256,35 +1256,35 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
   auto pb_at = [&](int r) { return *(GlobalF64c)(pb_s + (unsigned long long)((unsigned)r * 8u)); };
   auto pc_at = [&](int r) { return *(GlobalI32c)(pc_s + (unsigned long long)((unsigned)r * 4u)); };
   auto field_at = [&](int cell) { return __hip_atomic_load((GlobalF64)(a_s + (unsigned long long)((unsigned)cell * 8u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // Two register sets take turns as "this round's records" and "the next round's" (no copies between rounds); the compact lists
+  // are padded with zeros far enough (kPcStride) for a round to be requested ahead without asking whether the list has ended.
+  static_assert((kGroups + 1) * kGroup * kWave <= kPcStride, "the scan requests a round ahead");
   double cb[kGroup], nb[kGroup]; int cc[kGroup], nc[kGroup];
 #pragma unroll
   for (int j = 0; j < kGroup; ++j) { cb[j] = pb_at(j * kWave + lane); cc[j] = pc_at(j * kWave + lane); }
-#pragma nounroll
-  for (int g = 0; g < kGroups; ++g) {
-    if (g > 0 && !(readlane_f64(cb[0], 0) >= M * kKeep)) break;      // sorted descending: lane 0 holds the group's bound
-    double ap[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) ap[j] = field_at(cc[j]);
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-      const int ch = (g + 1) * kGroup + j;
-      nb[j] = 0.0; nc[j] = 0;
-      if (ch < kChunks) { nb[j] = pb_at(ch * kWave + lane); nc[j] = pc_at(ch * kWave + lane); }
-    }
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) {
-      const double v = cb[j] * ap[j];
-      const double key = __hiloint2double(__double2hiint(v), (__double2loint(v) & ~63) | (g * kGroup + j));
-      const bool larger = key > lm;
-      l2 = dmax(l2, dmin(lm, key));
-      lm = dmax(lm, key);
-      lcell = larger ? cc[j] : lcell;
-    }
-    M = __hiloint2double((int)wave_max_u32((unsigned)__double2hiint(lm)), 0);      // (scores are not negative: ordered like their bit patterns)
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) { cb[j] = nb[j]; cc[j] = nc[j]; }
-    K = (g + 1) * kGroup < kChunks ? (g + 1) * kGroup : kChunks;
+#define EG_SCAN_ROUND(CB, CC, NB, NC, g_)                                                                                        \
+  {                                                                                                                              \
+    if ((g_) >= kGroups || ((g_) > 0 && !(readlane_f64(CB[0], 0) >= M * kKeep))) break;      /* sorted descending: lane 0 holds the round's bound */ \
+    double ap[kGroup];                                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < kGroup; ++j) ap[j] = field_at(CC[j]);                                                  \
+    _Pragma("unroll") for (int j = 0; j < kGroup; ++j) { NB[j] = pb_at((((g_) + 1) * kGroup + j) * kWave + lane); NC[j] = pc_at((((g_) + 1) * kGroup + j) * kWave + lane); } \
+    _Pragma("unroll") for (int j = 0; j < kGroup; ++j) {                                                                         \
+      const double v = CB[j] * ap[j];                                                                                            \
+      const double key = __hiloint2double(__double2hiint(v), (__double2loint(v) & ~63) | ((g_) * kGroup + j));                   \
+      const bool larger = key > lm;                                                                                              \
+      l2 = dmax(l2, dmin(lm, key));                                                                                              \
+      lm = dmax(lm, key);                                                                                                        \
+      lcell = larger ? CC[j] : lcell;                                                                                            \
+    }                                                                                                                            \
+    M = __hiloint2double((int)wave_max_u32((unsigned)__double2hiint(lm)), 0);      /* (scores are not negative: ordered like their bit patterns) */ \
+    K = ((g_) + 1) * kGroup < kChunks ? ((g_) + 1) * kGroup : kChunks;                                                           \
   }
+#pragma nounroll
+  for (int g = 0;; g += 2) {
+    EG_SCAN_ROUND(cb, cc, nb, nc, g)
+    EG_SCAN_ROUND(nb, nc, cb, cc, g + 1)
+  }
+#undef EG_SCAN_ROUND
   M = wave_max_f64(lm);
   if (!(M >= 1e-250)) return kSearchFallback;      // (nothing placeable, or subnormal territory: the exact scan decides)
 #ifdef EG_STAMPS
@@ -1976,8 +1976,8 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
 #ifdef EG_STAMPS
             const unsigned long long th0 = __builtin_readcyclecounter();
 #endif
-            const size_t yv = (size_t)(yi * kMaxVariants + hv) * kPsStride;
-            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + yv), (unsigned long long)(T.pbase() + yv), (unsigned long long)(T.pcell() + yv), class_addr,
+            const size_t yv = (size_t)(yi * kMaxVariants + hv) * kPsStride, yc = (size_t)(yi * kMaxVariants + hv) * kPcStride;
+            const int hr = place_heavy<(kHelpers > 0)>((unsigned long long)(T.ps() + yv), (unsigned long long)(T.pbase() + yc), (unsigned long long)(T.pcell() + yc), class_addr,
                                                         tail.gen_cell, T.size_factor, lane, hrc, throughput_table(info), ep.ngen);
 #ifdef EG_STAMPS
             const unsigned long long th1 = __builtin_readcyclecounter();
