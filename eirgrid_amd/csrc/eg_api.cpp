@@ -841,8 +841,7 @@ int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_ow
   int lr = launch_apply_update(c->d_snap, d_packets, n_packets, (long long*)d_own_packet, noise_seed, c->out, c->last_n, c->last_first,
                                local_pick && n_packets == 1 && c->last_n > 0, c->d_list_len, nullptr);
   if (lr != 0) { set_error(std::string("k_apply_update launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  lr = launch_stalled_tables(c->d_snap, nullptr);
-  if (lr != 0) { set_error(std::string("k_stalled_tables launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
+  // (the stalled sampler's tables of the updated rows are rebuilt inside k_apply_update)
   return EG_OK;
 }
 }  // namespace

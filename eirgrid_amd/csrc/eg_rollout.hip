@@ -2280,11 +2280,8 @@ __global__ void __launch_bounds__(kWave) k_place_xy(DevTables T, int type, int y
 // Stalled sampler tables of a freshly uploaded snapshot (sampling.rs:190-220 on the un-nudged rows): per year the
 // weights in stable descending order raised to the power (shared eg_detpow), the permutation and the table-order sum.
 // One workgroup per year; runs on the stream right behind the snapshot copy.
-__global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base) {
-  __shared__ double s_w[64], s_scaled[64];
-  const int y = blockIdx.x, lane = threadIdx.x;
-  const uint32_t stall = reinterpret_cast<const DevState*>(snap_base + snap::state)->stall;
-  if (stall <= 500u) return;
+// (one wave per year; `s_w`, `s_scaled`: 64 doubles of LDS each, the wave's own)
+__device__ __forceinline__ void stalled_tables_year(uint8_t* snap_base, int y, int lane, uint32_t stall, double* s_w, double* s_scaled) {
   const double stagnation = rm::dmind((double)stall / 1000.0, 3.0);
   const double power = 1.0 + (2.0 * stagnation);
   double* row = reinterpret_cast<double*>(snap_base + snap::pol) + y * snap::kPolRow;
@@ -2292,20 +2289,27 @@ __global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base) {
   double* scaled = reinterpret_cast<double*>(snap_base + snap::scaled) + y * 64;
   uint8_t* perm = snap_base + snap::scaled_perm + y * 64;
   const double mine = lane < EG_N_ACTIONS ? w[lane] : 0.0;
+  wave_sync();
   s_w[lane] = mine;
-  __syncthreads();
+  wave_sync();
   if (lane < EG_N_ACTIONS) {
     int rank = 0;
     for (int b = 0; b < EG_N_ACTIONS; ++b) { const double o = s_w[b]; rank += (o > mine || (o == mine && b < lane)) ? 1 : 0; }
     const double v = eg_detpow(mine, power);
     s_scaled[rank] = v; scaled[rank] = v; perm[rank] = (uint8_t)lane;
   }
-  __syncthreads();
+  wave_sync();
   if (lane == 0) {
     double t = 0.0;
     for (int i = 0; i < EG_N_ACTIONS; ++i) t += s_scaled[i];
     row[snap::kPolScaledTotal] = t;
   }
+}
+__global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base) {
+  __shared__ double s_w[64], s_scaled[64];
+  const uint32_t stall = reinterpret_cast<const DevState*>(snap_base + snap::state)->stall;
+  if (stall <= 500u) return;
+  stalled_tables_year(snap_base, blockIdx.x, threadIdx.x, stall, s_w, s_scaled);
 }
 
 // statistics of a finished batch without re-running it (same accumulation as the k_rollout epilogue)
@@ -2687,6 +2691,12 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   if (tid == 0) dbg_t[6] = wall_clock64();
 #endif
   for (int i = tid; i < EG_STATS_LEN; i += 1024) zero_stats[i] = 0;
+  // the stalled sampler's tables of the rows as they are now (k_stalled_tables's work: a launch of its own — 5 us and a dependency gap
+  // behind every update, for something that only happens beyond 500 iterations without improvement — until round 3): a wave a year
+  if (st.stall > 500u) {
+    __shared__ double s_sw[16][64], s_ss[16][64];
+    for (int y = tid >> 6; y < Y; y += 16) stalled_tables_year(snap_base, y, tid & 63, st.stall, s_sw[tid >> 6], s_ss[tid >> 6]);
+  }
 #ifdef EG_STAMPS
   __syncthreads();      // the unused statistics slots 4..7 carry the phase durations out (after the zeroing above)
   if (tid == 0) {
