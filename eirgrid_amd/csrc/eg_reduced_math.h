@@ -44,8 +44,10 @@ EG_RM double score(const double* m) {
 // Everything a rollout / statistics kernel needs that depends only on the policy's scalars (learning.rs:37-55, :82,
 // :131-180; sampling.rs:425-427), evaluated wherever the policy changes: on the host at upload, on the device after an
 // on-device update.  The list flags and counters of `s` must be set by the caller.
-EG_RM void derive_state(DevState& s) {
-  const double k = (double)s.stall;
+// In four parts that write disjoint fields: the host runs them one after the other; k_apply_update gives each of the three with a
+// transcendental in it (a logarithm, a square root by powd, an exponential and a power: IEEE-only evaluations, about a microsecond or two
+// of one thread each) to a wave of its own.
+EG_RM void derive_state_score(DevState& s) {
   const double best_score = s.has_best ? score(s.best_metrics) : 0.0;
   // learning.rs:37-55: "relative improvement" compares the best score with itself (Q4)
   const double final_impact = best_score;
@@ -53,19 +55,28 @@ EG_RM void derive_state(DevState& s) {
   if (s.has_best) rel = best_score > 0.0 ? (final_impact - best_score) / best_score : final_impact;
   s.rel_improvement = rel;
   s.immediate_weight = rel > 0.0 ? 0.7 : 0.3;
-  s.noop_boost = (s.has_best && s.best_metrics[0] <= 0.0 && s.best_metrics[2] > kMaxCost * 8.0) ? 1 : 0;   // learning.rs:82
+  s.p_best_score = best_score;
+}
+EG_RM void derive_state_heur(DevState& s) {
   const double scaled = powd(s.exploration_rate, 0.5);                                                     // sampling.rs:425-427
   const double lo = 2.0 / scaled, hi = 12.0 / scaled;
   s.heur_min = (uint32_t)(long long)(lo + 0.5); s.heur_max = (uint32_t)(long long)(hi + 0.5);               // f64::round, x > 0
-  s.p_best_score = best_score;
+}
+EG_RM void derive_state_contrast(DevState& s) {
+  const double k = (double)s.stall;
   s.p_threshold = 0.1 * dmaxd(expd(-k / 500.0), 0.00001 / 0.1);                                           // learning.rs:146-154
-  s.p_forced = s.stall > 800u ? 1 : 0;
   s.p_stagnation = 1.0 + (0.2 * powd(k / 10.0, 1.8));                                                     // learning.rs:163-164
+}
+EG_RM void derive_state_rest(DevState& s) {
+  const double k = (double)s.stall;
+  s.noop_boost = (s.has_best && s.best_metrics[0] <= 0.0 && s.best_metrics[2] > kMaxCost * 8.0) ? 1 : 0;   // learning.rs:82
+  s.p_forced = s.stall > 800u ? 1 : 0;
   s.p_adaptive_lr = s.learning_rate * (1.0 + 0.1 * k);                                                    // learning.rs:174
   s.boost_others = 1.0 + (s.learning_rate * 0.1); s.boost_noop = 1.0 + s.learning_rate * 0.2;             // learning.rs:74-87
   s.eps_main = s.stall > 100u ? s.exploration_rate * (1.0 / (1.0 + 0.01 * k)) : s.exploration_rate;       // sampling.rs:150-157
   s.scaled_power = 1.0 + (2.0 * dmind(k / 1000.0, 3.0));                                                  // sampling.rs:193-195
 }
+EG_RM void derive_state(DevState& s) { derive_state_score(s); derive_state_heur(s); derive_state_contrast(s); derive_state_rest(s); }
 
 // apply_contrast_learning in log space (learning.rs:131-255): the boost of one occurrence in the best lists
 EG_RM double contrast_ln_boost(double learning_rate, uint32_t stall) {

@@ -2670,23 +2670,41 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 #endif
 
   // ---- what eg_upload_snapshot derives: row sums in table order, scalars ----
-  if (tid < Y) {
-    double* row = pol + tid * snap::kPolRow;
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < NA; ++i) a += row[i];
-    for (int i = 0; i < 14; ++i) b += row[snap::kPolDw + i];
-    row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
+  // (the rows come to LDS with one load per thread and entry; a thread a year then adds its 61 + 14 entries in table order from
+  //  there — summed straight from global memory, 75 dependent-latency loads per thread, this was 10 of the kernel's 22 us)
+  __shared__ double s_scratch[2 * 16 * 64];      // [26][76] here; the stalled sampler's per-wave tables further down
+  {
+    constexpr int kPer = NA + 14 + 1;      // 76: a row's main weights, its first 14 deficit weights, padding
+    for (int i = tid; i < Y * (NA + 14); i += 1024) {
+      const int y = i / (NA + 14), k = i - y * (NA + 14);
+      s_scratch[y * kPer + k] = pol[y * snap::kPolRow + (k < NA ? k : snap::kPolDw + (k - NA))];
+    }
+    __syncthreads();
+    if (tid < Y) {
+      const double* r = s_scratch + tid * kPer;
+      double a = 0.0, b = 0.0;
+      for (int i = 0; i < NA; ++i) a += r[i];
+      for (int i = 0; i < 14; ++i) b += r[NA + i];
+      double* row = pol + tid * snap::kPolRow;
+      row[snap::kPolTotMain] = a; row[snap::kPolTotDeficit] = b;      // the count row is never nudged: its sum stays
+    }
   }
-  if (tid == 64) { rm::derive_state(st); *gstate = st; }            // beside the row sums of wave 0
+  // (derive_state in its four parts, a wave each, beside the row sums of wave 0; the state goes out behind the next barrier)
+  if (tid == 64) rm::derive_state_score(st);
+  if (tid == 128) rm::derive_state_heur(st);
+  if (tid == 192) rm::derive_state_contrast(st);
+  if (tid == 256) rm::derive_state_rest(st);
   // the length of the best list goes to a pinned host word: the host plans its launches by it (which replay variant is the long
   // pole, whether a field pool is needed) without ever waiting for the device
-  if (tid == 65 && list_len_out) {
-    const uint32_t len = st.has_lists ? (uint32_t)(s_improved != 0 ? s_prefix[0][Y] : s_off[0][Y]) : 0u;
+  // (only when the list has changed — an improvement —: a store to host memory is a PCIe write the kernel's end waits for)
+  if (tid == 65 && list_len_out && s_improved != 0) {
+    const uint32_t len = st.has_lists ? (uint32_t)s_prefix[0][Y] : 0u;
     __hip_atomic_store(list_len_out, len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // this rank's statistics buffer is ready for the next batch's epilogue (when it is also `packets`, every read of it
   // happened before the barriers above)
   __syncthreads();
+  if (tid == 64) *gstate = st;
 #ifdef EG_STAMPS
   if (tid == 0) dbg_t[6] = wall_clock64();
 #endif
@@ -2694,8 +2712,9 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
   // the stalled sampler's tables of the rows as they are now (k_stalled_tables's work: a launch of its own — 5 us and a dependency gap
   // behind every update, for something that only happens beyond 500 iterations without improvement — until round 3): a wave a year
   if (st.stall > 500u) {
-    __shared__ double s_sw[16][64], s_ss[16][64];
-    for (int y = tid >> 6; y < Y; y += 16) stalled_tables_year(snap_base, y, tid & 63, st.stall, s_sw[tid >> 6], s_ss[tid >> 6]);
+    static_assert(Y * (NA + 15) <= 2 * 16 * 64, "one LDS buffer serves the row sums and the stalled tables");
+    double* s_sw = s_scratch + (tid >> 6) * 64; double* s_ss = s_scratch + 16 * 64 + (tid >> 6) * 64;      // (the barrier above is behind the row sums)
+    for (int y = tid >> 6; y < Y; y += 16) stalled_tables_year(snap_base, y, tid & 63, st.stall, s_sw, s_ss);
   }
 #ifdef EG_STAMPS
   __syncthreads();      // the unused statistics slots 4..7 carry the phase durations out (after the zeroing above)
