@@ -2518,8 +2518,11 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
     if (win >= 0) {
       if (tid < 4) cw->metrics[tid] = O.metrics(win)[tid];
       if (tid < EG_YEARS) { cw->n_run[tid] = O.n_run(win)[tid]; cw->n_def[tid] = O.n_def(win)[tid]; }
-      for (int i = tid; i < EG_RUN_CAP; i += 1024) cw->run_log[i] = O.run_log(win)[i];
-      for (int i = tid; i < EG_DEF_CAP; i += 1024) cw->def_log[i] = O.def_log(win)[i];
+      // (four bytes a thread: the lists start at multiples of four in the record and in the packet)
+      static_assert(rec::run_log % 4 == 0 && rec::def_log % 4 == 0 && rec::stride % 4 == 0 && offsetof(UpdateCandidate, run_log) % 4 == 0 &&
+                    offsetof(UpdateCandidate, def_log) % 4 == 0 && EG_RUN_CAP % 4 == 0 && EG_DEF_CAP % 4 == 0, "word copies of the winner's lists");
+      for (int i = tid; i < EG_RUN_CAP / 4; i += 1024) reinterpret_cast<uint32_t*>(cw->run_log)[i] = reinterpret_cast<const uint32_t*>(O.run_log(win))[i];
+      for (int i = tid; i < EG_DEF_CAP / 4; i += 1024) reinterpret_cast<uint32_t*>(cw->def_log)[i] = reinterpret_cast<const uint32_t*>(O.def_log(win))[i];
     }
     __syncthreads();      // the record is in place for every thread of this workgroup
   }
