@@ -8,7 +8,7 @@ sampling.rs:78-145), the rest sampling from the policy; the best strategy the fi
 (configs[3]: 8 x 16 384 = 131 072 episodes per update) and the update needs ONE collective.
 
 A batch pass = the whole hot path with the policy resident on the device: k_rollout (the episodes + the batch-update
-statistics in its epilogue), when N > 1 k_pick_best + ONE RCCL all-gather of every rank's 32 KB update packet, k_apply_update
+statistics in its epilogue), when N > 1 k_pick_best + ONE RCCL all-gather of every rank's 37 008-byte update packet, k_apply_update
 (the batch form of the reference's write-locked update, multi_simulation.rs:494-508), k_stalled_tables — stream-ordered
 launches, no host synchronisation, world tables and policy resident in HBM before the timed region starts.
 A STEP = `batches_per_step` consecutive batch passes; the number is chosen once, from a calibration of untimed passes,
@@ -321,6 +321,7 @@ def main():
     from eirgrid_amd import synthetic_world
     from eirgrid_amd.engine import ActionWeights, Engine
     from eirgrid_amd.parallel import BatchTrainer
+    from eirgrid_amd._native import PACKET_BYTES as N_PACKET_BYTES
 
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -454,7 +455,7 @@ def main():
                                      "S=130 settlements / G0=59 existing plant / P=200 coast points, seed 12345",
                        "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction,
                        "batches_timed": m["batches"], "episodes_failed": m["failed"],
-                       "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one 32 KB all-gather per update "
+                       "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one all-gather of {N_PACKET_BYTES} bytes per rank per update "
                                       "(integer statistics summed in the update kernel)",
                        "last_batch": {k: census[k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
                                                              "generators_per_seeded_episode", "generators_per_replay_episode")},

@@ -68,7 +68,7 @@ struct eg_ctx {
   // the list since the host last looked — both variants are launched and decide for themselves — and the hint only orders the
   // launches; it follows the device through `h_list_len`, a pinned host word that k_apply_update and k_rewind write the list's
   // length to (read without synchronising: as old as the launch queue is deep).
-  bool long_list_hint = false, long_list_hint_held = false, list_exact = false;
+  bool long_list_hint = false, long_list_hint_held = false, list_exact = false, list_exact_held = false;
   uint32_t* h_list_len = nullptr; uint32_t* d_list_len = nullptr;      // the same pinned word, host and device address
   DevSnapshot snap{};
   bool snap_valid = false;
@@ -104,6 +104,12 @@ struct eg_ctx {
   uint32_t heavy_slots_max = uint32_t((size_t(64) << 30) / (size_t(kRadiusClasses) * 2624 * sizeof(double)));
   uint32_t heavy_slots_wanted = 4096, launch_epoch = 0;
   bool heavy_slots_auto = true;      // (EIRGRID_HEAVY_SLOTS fixes the pool size instead)
+  // replay hoist (eg_replay_coop.h; eg_replay_hoist / EIRGRID_REPLAY_HOIST=1): the replay episodes of a batch computed once.
+  // d_hoist: {u64 sequence number of the last batch whose hoist succeeded, i32 lengths[5]}; d_coop: the scratch record.
+  bool hoist_on = false, hoist_supported = false;
+  unsigned long long hoist_seq = 0;
+  unsigned long long* d_hoist = nullptr; uint8_t* d_coop = nullptr;
+  uint64_t hoist_batches = 0;      // batches launched with the hoist armed (eg_replay_hoist_stats)
 };
 
 namespace {
@@ -241,6 +247,10 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   plan.skip_long = c->list_exact && !list_long;
   int rc = prepare_heavy(c, plan.n_heavy, plan.skip_long);
   if (rc != EG_OK) return rc;
+  if (c->hoist_on && plan.n_heavy > 0) {      // the replay episodes of this batch are computed once (eg_replay_coop.h)
+    plan.hoist_seq = ++c->hoist_seq; plan.d_hoist = c->d_hoist; plan.coop_out = c->d_coop;
+    c->hoist_batches += 1;
+  }
   if (split) {
     EG_HIP(hipEventRecord(c->ev_fork[slot], nullptr));
     EG_HIP(hipStreamWaitEvent(c->stream_heavy, c->ev_fork[slot], 0));
@@ -249,7 +259,8 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
     // the lean grid then waits for an event recorded behind the short-replay variant — which has nothing to do and is gone
     // in microseconds — i.e. until the long variant is being dispatched.  With short replays (or when the host's idea of the
     // list is out of date) nobody waits for anybody.
-    if (list_long) plan.go_event = c->ev_go[slot];
+    // (the hoisted replay is one workgroup that needs a whole CU: it is dispatched ahead of the lean grid in any case)
+    if (list_long || plan.hoist_seq != 0ull) plan.go_event = c->ev_go[slot];
   }
   const int lr = launch_rollout(c->dev, c->snap, c->out, seed, first_index, n, d_mask, period, d_stats, plan);
   if (lr != 0) { set_error(std::string("k_rollout launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
@@ -323,6 +334,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
   put(blob, tab::dr, H.dr, size_t(kRadiusClasses) * 169); put(blob, tab::m03, H.m03, kCells); put(blob, tab::t12, H.t12, size_t(kYears) * kTypes);
   put(blob, tab::offv, H.offv, size_t(kYears) * kOffsetTypes * kYears); put(blob, tab::offc, H.offc, size_t(kYears) * kOffsetTypes * kMults);
   put(blob, tab::cc, H.cc, size_t(kYears) * kTypes * kYears * kMults * 2);
+  put(blob, tab::te_cell, H.te, size_t(kYears) * kRadiusClasses * kCells); put(blob, tab::coastf, H.coastf, kCells);
   {  // Sorted candidate lists.  final(c) = ((te[c] * prod_g d/R) * cf[c]) * size <= base(c) = (te[c] * cf[c]) * size
      // because every factor is in [0, 1] and IEEE multiplication is monotone, so a scan in descending base order can
      // stop as soon as the next base is below the best final score found (k_rollout / place_search).
@@ -396,6 +408,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
           ++nbox;
         }
     if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
+    c->hoist_supported = nbox <= 1024;                // (the hoisted replay updates its field with one lane per entry of this list)
     for (int i = nbox; i < 1024; ++i) box[i] = 145u << 10;      // padding: class 0, di = dj = -16 (no class reaches that far), q = 145 (factor 1.0)
     for (int k = 0, i = 0; k <= kRadiusClasses; ++k) {      // words 1024..1030: where class k starts (the list is sorted by class), then the end
       while (i < nbox && i < 1024 && int(box[i] >> 19) < k) ++i;
@@ -461,6 +474,13 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       if (hipHostGetDevicePointer((void**)&c->d_list_len, c->h_list_len, 0) != hipSuccess) { (void)hipGetLastError(); c->d_list_len = nullptr; }
     } else { (void)hipGetLastError(); c->h_list_len = nullptr; }
   }
+  if (rc == EG_OK) {
+    if (hipMalloc((void**)&c->d_hoist, kHoistBytes) != hipSuccess || hipMalloc((void**)&c->d_coop, rec::stride) != hipSuccess ||
+        hipMemset(c->d_hoist, 0, kHoistBytes) != hipSuccess || hipMemset(c->d_coop, 0, rec::stride) != hipSuccess) {
+      set_error("hipMalloc(replay hoist) failed"); rc = EG_ERR_HIP;
+    }
+    if (const char* rh = std::getenv("EIRGRID_REPLAY_HOIST")) c->hoist_on = c->hoist_supported && rh[0] == '1';
+  }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
 }
@@ -473,6 +493,8 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_snap) (void)hipFree(c->d_snap);
   if (c->d_snap_held) (void)hipFree(c->d_snap_held);
   if (c->d_fold) (void)hipFree(c->d_fold);
+  if (c->d_hoist) (void)hipFree(c->d_hoist);
+  if (c->d_coop) (void)hipFree(c->d_coop);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->h_list_len) (void)hipHostFree(c->h_list_len);
   if (c->d_mask) (void)hipFree(c->d_mask);
@@ -553,6 +575,8 @@ int32_t eg_upload_snapshot(eg_ctx* c, const eg_policy_snapshot* s, const eg_opts
   std::memcpy(h + snap::best_mask, mask, sizeof(mask)); std::memcpy(h + snap::bestd_mask, dmask, sizeof(dmask));
   std::memcpy(h + snap::best_off, off, sizeof(off)); std::memcpy(h + snap::bestd_off, offd, sizeof(offd));
   c->long_list_hint = have_lists && off[26] > kShortReplayMax; c->list_exact = true;
+  // (the pinned word is a HINT only — read when list_exact is false, to order the launches: an update or rewind kernel enqueued before
+  //  this upload may still store an older length over this one; nothing but the launch order ever depends on it)
   if (c->h_list_len) *(volatile uint32_t*)c->h_list_len = have_lists ? uint32_t(off[26]) : 0u;
   if (have_lists) { std::memcpy(h + snap::best_actions, s->best_actions, size_t(off[26])); std::memcpy(h + snap::bestd_actions, s->best_deficit_actions, size_t(offd[26])); }
   {  // the policy's scalars as the kernels read them (snap::state)
@@ -626,11 +650,14 @@ namespace {
 // One strided copy per requested field: episode records are rec::stride bytes apart on the device.  The lists of a record have the
 // oracle's capacity (4 096 entries: 41.6 KB per episode), an episode fills a fraction of it (a sampled one about 1 KB): the counts
 // come first, and every list is then copied only as wide as the longest of the batch needs — the caller's rows keep their full
-// pitch, what lies behind an episode's entries is left as the caller passed it.  (EIRGRID_FETCH_FULL=1: whole rows, for the
+// pitch, what lies behind an episode's entries is left as the caller passed it — except for the single-record fetches (N == 1:
+// eg_fetch_record, eg_fetch_best_run, eg_fetch_best_result), whose rows are zeroed behind the entries: a C caller with an
+// uninitialised buffer gets a defined row there, and it costs nothing.  (EIRGRID_FETCH_FULL=1: whole rows, for the
 // diagnostic builds that park their cycle stamps at the end of act_log.)
 int fetch_records(const uint8_t* d_base, size_t N, eg_episode_out* o) {
 #define EG_GET_W(field, count, type, used) \
-  if (o->field && (used) > 0) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), d_base + rec::field, rec::stride, (used) * sizeof(type), N, hipMemcpyDeviceToHost))
+  if (o->field && (used) > 0) EG_HIP(hipMemcpy2D(o->field, (count) * sizeof(type), d_base + rec::field, rec::stride, (used) * sizeof(type), N, hipMemcpyDeviceToHost)); \
+  if (o->field && N == 1 && size_t(used) < size_t(count)) std::memset(o->field + (used), 0, (size_t(count) - size_t(used)) * sizeof(type))      /* one record: its rows end in zeros */
 #define EG_GET(field, count, type) EG_GET_W(field, count, type, count)
   EG_GET(metrics, 4, double); EG_GET(yearly, EG_YEARS * EG_YEARLY_FIELDS, double); EG_GET(status, 1, int32_t);
   EG_GET(n_gens, 1, int32_t); EG_GET(n_offsets, 1, int32_t);
@@ -846,12 +873,33 @@ int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_ow
 }
 }  // namespace
 
+int32_t eg_replay_hoist(eg_ctx* c, int32_t on) {
+  if (!c) { set_error("eg_replay_hoist: bad argument"); return EG_ERR_BAD_ARG; }
+  if (on && !c->hoist_supported) { set_error("eg_replay_hoist: this world's penalty radii exceed the field-update list (no hoist)"); return EG_ERR_UNSUPPORTED; }
+  c->hoist_on = on != 0;
+  return EG_OK;
+}
+
+int32_t eg_replay_hoist_stats(eg_ctx* c, uint64_t* batches_armed, int32_t* last_batch_hoisted) {
+  if (!c) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipDeviceSynchronize());
+  unsigned long long word = 0;
+  EG_HIP(hipMemcpy(&word, c->d_hoist, sizeof(word), hipMemcpyDeviceToHost));
+  if (batches_armed) *batches_armed = c->hoist_batches;
+  if (last_batch_hoisted) *last_batch_hoisted = (c->hoist_seq != 0ull && word == c->hoist_seq) ? 1 : 0;
+  return EG_OK;
+}
+
 int32_t eg_policy_hold(eg_ctx* c) {
   if (!c || !c->snap_valid) { set_error("eg_policy_hold: push a policy first"); return EG_ERR_BAD_ARG; }
   EG_HIP(hipSetDevice(c->device));
   if (!c->d_snap_held) EG_HIP(hipMalloc((void**)&c->d_snap_held, snap::total));
   EG_HIP(hipMemcpyAsync(c->d_snap_held, c->d_snap, snap::total, hipMemcpyDeviceToDevice, nullptr));
-  c->long_list_hint_held = c->long_list_hint && c->list_exact;      // (hold is called on a policy the host has just pushed or pulled)
+  // What the host knows about the list it is holding travels with the copy: a hold behind on-device updates that nobody has pulled
+  // (list_exact == false) must not come back from a rewind as "known to be short" — the long-replay variant would not be launched
+  // and the replay episodes' records would keep the previous batch's bytes.
+  c->long_list_hint_held = c->long_list_hint; c->list_exact_held = c->list_exact;
   return EG_OK;
 }
 
@@ -861,7 +909,9 @@ int32_t eg_policy_rewind(eg_ctx* c) {
   // (the count of failed episodes is a diagnostic of the run, not policy: it goes on counting; one small kernel instead of two copies)
   const int lr = launch_rewind(c->d_snap, c->d_snap_held, c->d_list_len, nullptr);
   if (lr != 0) { set_error(std::string("k_rewind launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
-  c->long_list_hint = c->long_list_hint_held; c->list_exact = true;      // the next launch finds the held policy's list
+  // the next launch finds the held policy's list: the host knows it exactly when it knew it at the hold; otherwise both replay
+  // variants are launched and decide on the device (k_rewind publishes the held list's length through the pinned word for the order)
+  c->long_list_hint = c->long_list_hint_held; c->list_exact = c->list_exact_held;
   return EG_OK;
 }
 

@@ -116,7 +116,11 @@ constexpr size_t pcell = a16(pbase + 8 * size_t(kYears) * kMaxVariants * kPcStri
 // padded to a multiple of four entries per lane; hv_quads = that multiple.  (The small-batch kernel packs its own list into LDS.)
 constexpr size_t hv_lists = a16(pcell + 4 * size_t(kYears) * kMaxVariants * kPcStride);     // u32 [64][1024]
 constexpr size_t hv_quads = a16(hv_lists + 4 * size_t(64) * 1024);                          // i32 [64]
-constexpr size_t total = hv_quads + 4 * 64;
+// the placement prefix per CELL (HostTables::te, coastf): what the hoisted replay (eg_replay_coop.h) reads — its sixteen waves hold
+// every cell of the grid at once, so it wants the candidates in cell order, not sorted
+constexpr size_t te_cell = a16(hv_quads + 4 * 64);                                          // f64 [26][6][2601]
+constexpr size_t coastf = a16(te_cell + 8 * size_t(kYears) * kRadiusClasses * kCells);      // f64 [2601]
+constexpr size_t total = a16(coastf + 8 * size_t(kCells));
 }  // namespace tab
 
 struct DevTables {
@@ -137,6 +141,7 @@ struct DevTables {
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
   EG_TAB(ps, PsRec) EG_TAB(pbase, double) EG_TAB(pcell, uint32_t) EG_TAB(hv_lists, uint32_t) EG_TAB(hv_quads, int32_t) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
+  EG_TAB(te_cell, double) EG_TAB(coastf, double)
 #undef EG_TAB
 };
 
@@ -282,7 +287,15 @@ struct RolloutPlan {
   const uint32_t* d_index;
   uint32_t off, period;
   void* ev[4];
+  // replay hoist (eg_replay_coop.h): hoist_seq != 0 = the replay episodes of this batch are computed ONCE by k_replay_coop into the
+  // scratch record `coop_out` and copied to every replay slot by k_replay_broadcast; d_hoist = {u64 word: the sequence number of the
+  // last batch whose hoist succeeded, i32 lengths[8]} — the per-episode replay variants are launched in between and return at once
+  // when the word says their batch has been served
+  unsigned long long hoist_seq;
+  unsigned long long* d_hoist;
+  uint8_t* coop_out;
 };
+constexpr size_t kHoistBytes = 64;      // d_hoist: u64 word | i32 lengths {run, def, act, gens, offsets}
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& plan);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook

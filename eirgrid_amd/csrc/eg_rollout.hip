@@ -638,22 +638,33 @@ __device__ __forceinline__ int list_cell(unsigned long long tail_cells, int gb, 
 // acc + x[lane J of the row], in every lane of that row.  gfx90a and later have a DPP form of the VOP2 double-precision
 // multiply-accumulate (row_newbcast only; v_add_f64 is VOP3 and has none): acc = x[J] * 1.0 + acc is that addition — the product is
 // exact and the sum is rounded once — so a sum in list order over 16 lanes is 16 instructions, instead of 16 x (two v_readlane + one
-// add) through scalar registers.  (Inline assembly is opaque to the hazard recogniser: fold_row16 starts with the wait states a DPP
-// read needs after a VALU write of the register or of EXEC.)
-template <int J>
-__device__ __forceinline__ void add_row_lane(double& acc, double x, double one) {
-  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(one), "n"(J));
-}
+// add) through scalar registers.
+// Inline assembly is opaque to the hazard recogniser: a DPP read needs wait states after a VALU write of the register it reads (2) or
+// of EXEC (5).  The s_nop and the sixteen accumulations are therefore ONE asm statement with x as an input: whatever produces x, and
+// whatever the compiler schedules in front of the statement, is followed by the five wait states before the first DPP read — two
+// statements (a bare s_nop, then the DPP instructions) left the scheduler free to put the producer of x between them.
+#define EG_FMAC_DPP(acc_, x_, j_) "v_fmac_f64_dpp " acc_ ", " x_ ", %[one] row_newbcast:" #j_ " row_mask:0xf bank_mask:0xf\n\t"
 // acc (the same value in every lane) + x[16 row + 0] + ... + x[16 row + 15], added in that order; valid in the lanes of each row for
 // that row's sixteen values
 __device__ __forceinline__ double fold_row16(double acc, double x) {
   const double one = 1.0;
-  asm volatile("s_nop 4" ::: "memory");
-  add_row_lane<0>(acc, x, one); add_row_lane<1>(acc, x, one); add_row_lane<2>(acc, x, one); add_row_lane<3>(acc, x, one);
-  add_row_lane<4>(acc, x, one); add_row_lane<5>(acc, x, one); add_row_lane<6>(acc, x, one); add_row_lane<7>(acc, x, one);
-  add_row_lane<8>(acc, x, one); add_row_lane<9>(acc, x, one); add_row_lane<10>(acc, x, one); add_row_lane<11>(acc, x, one);
-  add_row_lane<12>(acc, x, one); add_row_lane<13>(acc, x, one); add_row_lane<14>(acc, x, one); add_row_lane<15>(acc, x, one);
+  asm("s_nop 4\n\t"
+      EG_FMAC_DPP("%[a]", "%[x]", 0) EG_FMAC_DPP("%[a]", "%[x]", 1) EG_FMAC_DPP("%[a]", "%[x]", 2) EG_FMAC_DPP("%[a]", "%[x]", 3)
+      EG_FMAC_DPP("%[a]", "%[x]", 4) EG_FMAC_DPP("%[a]", "%[x]", 5) EG_FMAC_DPP("%[a]", "%[x]", 6) EG_FMAC_DPP("%[a]", "%[x]", 7)
+      EG_FMAC_DPP("%[a]", "%[x]", 8) EG_FMAC_DPP("%[a]", "%[x]", 9) EG_FMAC_DPP("%[a]", "%[x]", 10) EG_FMAC_DPP("%[a]", "%[x]", 11)
+      EG_FMAC_DPP("%[a]", "%[x]", 12) EG_FMAC_DPP("%[a]", "%[x]", 13) EG_FMAC_DPP("%[a]", "%[x]", 14) EG_FMAC_DPP("%[a]", "%[x]", 15)
+      : [a] "+v"(acc) : [x] "v"(x), [one] "v"(one));
   return acc;
+}
+// two such sums side by side (the two chains are independent: interleaved, neither waits for the other's accumulation)
+__device__ __forceinline__ void fold2_row16(double& a, double xa, double& b, double xb) {
+  const double one = 1.0;
+#define EG_FMAC2(j_) EG_FMAC_DPP("%[a]", "%[xa]", j_) EG_FMAC_DPP("%[b]", "%[xb]", j_)
+  asm("s_nop 4\n\t"
+      EG_FMAC2(0) EG_FMAC2(1) EG_FMAC2(2) EG_FMAC2(3) EG_FMAC2(4) EG_FMAC2(5) EG_FMAC2(6) EG_FMAC2(7)
+      EG_FMAC2(8) EG_FMAC2(9) EG_FMAC2(10) EG_FMAC2(11) EG_FMAC2(12) EG_FMAC2(13) EG_FMAC2(14) EG_FMAC2(15)
+      : [a] "+v"(a), [b] "+v"(b) : [xa] "v"(xa), [xb] "v"(xb), [one] "v"(one));
+#undef EG_FMAC2
 }
 
 struct YearTerms { double2 g_cc; double g_m03, g_t12, o_v, o_c; int g_t; };
@@ -723,7 +734,8 @@ __device__ __forceinline__ void year_fold(const DevTables& T, int lane, int yi, 
       {      // sixteen generators at a time through the DPP adder (a row padded with +0.0: sums of positive terms, x + 0.0 == x)
         const double cz = lane < cnt ? cc.x : 0.0, oz = lane < cnt ? op : 0.0;
         for (; cnt - j >= 7; j += 16) {      // (below seven generators the scalar path is fewer instructions)
-          const double ag = fold_row16(s.gcost, cz), ao = fold_row16(s.optot, oz);
+          double ag = s.gcost, ao = s.optot;
+          fold2_row16(ag, cz, ao, oz);
           s.gcost = readlane_f64(ag, j); s.optot = readlane_f64(ao, j);      // lane j = the first lane of the row just folded
         }
       }
@@ -1628,6 +1640,10 @@ struct EpisodeMap {
   const uint32_t* index;      // mode 1: episode = index[workgroup]
   uint32_t mode;              // 0: the workgroup index; 2: off + period * workgroup (the replays of a period); 3: the others
   uint32_t count, off, period;
+  // replay hoist (eg_replay_coop.h): when *hoist carries this launch's sequence number, k_replay_coop has computed the batch's replay
+  // episodes once and k_replay_broadcast hands every one of them the record: the replay variants have nothing to do (0: no hoist)
+  const unsigned long long* hoist;
+  unsigned long long hoist_seq;
 };
 __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b) {
   if (m.mode == 0u) return b;
@@ -1676,6 +1692,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   if constexpr (kReplay) {      // (uniform for the whole grid)
     const bool long_list = S_in.state()->has_lists && S_in.best_off()[EG_YEARS] > kShortReplayMax;
     if (long_list != kHeavy) return;
+    if (emap.hoist_seq != 0ull && *emap.hoist == emap.hoist_seq) return;      // served by k_replay_coop / k_replay_broadcast
   }
   const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
@@ -2231,6 +2248,8 @@ __global__ void __launch_bounds__(kWave, 7) k_heavy_register_budget(unsigned lon
 #endif
 
 #ifndef EG_TU_THROUGHPUT      // (everything from here to the launchers lives in eg_rollout.o only)
+#include "eg_replay_coop.h"      // k_replay_coop, k_replay_broadcast: the replay episodes of a batch, computed once
+
 // ---- B2: a single placement search, for parity tests of the arg-max --------------------------------------------
 __global__ void __launch_bounds__(kWave) k_place(DevTables T, int type, int yi, const uint16_t* __restrict__ cells,
                                                  int n_extra, int32_t* out_cell, double* out_score) {
@@ -2737,13 +2756,15 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 // the throughput kernels (one wave per episode), from their own object (see the top of the kernel section)
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
-                              const uint32_t* index, uint32_t off, uint32_t period, void* stream, void* ev0, void* ev1);
+                              const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
+                              void* stream, void* ev0, void* ev1);
 #ifdef EG_TU_THROUGHPUT
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
-                              const uint32_t* index, uint32_t off, uint32_t period, void* stream, void* ev0, void* ev1) {
+                              const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
+                              void* stream, void* ev0, void* ev1) {
   EpisodeMap map{};
-  map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period;
+  map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period; map.hoist = hoist; map.hoist_seq = hoist_seq;
   // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
 #define EG_LAUNCH_TP(kKind) hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, \
                                                   t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map)
@@ -2763,7 +2784,8 @@ void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s,
                           (hipEvent_t)ev0, (hipEvent_t)ev1, 0, t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n,
                           d_replay_mask, replay_period, d_stats, map);
   else
-    (void)launch_rollout_throughput(kKind, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, map.count, map.mode, map.index, map.off, map.period, stream, ev0, ev1);
+    (void)launch_rollout_throughput(kKind, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, map.count, map.mode, map.index, map.off, map.period,
+                                    map.hoist, map.hoist_seq, stream, ev0, ev1);
 }
 }  // namespace
 
@@ -2776,17 +2798,36 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     if (p.n_lean == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index; }
     else { m.mode = 2u; m.off = p.off; m.period = p.period; }
+    const bool hoist = p.hoist_seq != 0ull;
+    if (hoist) {
+      // Replay hoist: ONE workgroup computes the batch's replay script (k_replay_coop, sixteen waves and the whole LDS of a CU — it must
+      // be dispatched BEFORE the lean grid fills every CU: the lean grid's stream waits for an event recorded right in front of it),
+      // the per-episode variants follow and return at once when it has succeeded, k_replay_broadcast hands out the record.
+      m.hoist = p.d_hoist; m.hoist_seq = p.hoist_seq;
+      if (p.go_event && p.n_lean > 0) {
+        (void)hipEventRecord((hipEvent_t)p.go_event, (hipStream_t)p.stream_heavy);
+        (void)hipStreamWaitEvent((hipStream_t)p.stream_lean, (hipEvent_t)p.go_event, 0);
+      }
+      const DevOut scratch{p.coop_out, nullptr};
+      hipExtLaunchKernelGGL(k_replay_coop, dim3(1), dim3(coop::kThreads), 0, (hipStream_t)p.stream_heavy, (hipEvent_t)p.ev[0], nullptr, 0,
+                            t, s, scratch, p.hoist_seq, p.d_hoist);
+    }
     // (the short one first: when it is the one that returns at once it finds the chip empty and is gone in microseconds; a
     //  256-register wave of the long one, when IT has nothing to do, must wait until a SIMD full of lean waves has drained two
     //  of them, and whatever is queued behind it on the stream waits with it — measured: 0.6 ms)
-    launch_variant<kReplayShort>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, p.ev[0], nullptr);
-    if (p.go_event && p.n_lean > 0) {
+    launch_variant<kReplayShort>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, hoist ? nullptr : p.ev[0], nullptr);
+    if (!hoist && p.go_event && p.n_lean > 0) {
       (void)hipEventRecord((hipEvent_t)p.go_event, (hipStream_t)p.stream_heavy);
       (void)hipStreamWaitEvent((hipStream_t)p.stream_lean, (hipEvent_t)p.go_event, 0);
     }
     // (the short variant's launch carries the start event, the long one's the stop event; without the long one a marker does)
-    if (!p.skip_long) launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, p.ev[1]);
-    else (void)hipEventRecord((hipEvent_t)p.ev[1], (hipStream_t)p.stream_heavy);
+    if (!p.skip_long) launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, hoist ? nullptr : p.ev[1]);
+    else if (!hoist) (void)hipEventRecord((hipEvent_t)p.ev[1], (hipStream_t)p.stream_heavy);
+    if (hoist) {
+      const DevOut scratch{p.coop_out, nullptr};
+      hipExtLaunchKernelGGL(k_replay_broadcast, dim3(m.count), dim3(kWave), 0, (hipStream_t)p.stream_heavy, nullptr, (hipEvent_t)p.ev[1], 0,
+                            s, scratch, o, n, d_stats, m, (const unsigned long long*)p.d_hoist, p.hoist_seq);
+    }
   }
   if (p.n_lean > 0) {
     EpisodeMap m{};

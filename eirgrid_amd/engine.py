@@ -383,6 +383,16 @@ class Engine:
         """Put the held copy back (eg_policy_rewind)."""
         N.check(N.lib().eg_policy_rewind(self.h), "eg_policy_rewind")
 
+    def replay_hoist(self, on: bool = True) -> None:
+        """Compute the replay episodes of every batch once instead of once per episode (eg_replay_hoist; include/eirgrid_hip.h)."""
+        N.check(N.lib().eg_replay_hoist(self.h, int(bool(on))), "eg_replay_hoist")
+
+    def replay_hoist_stats(self):
+        """(batches launched with the hoist armed, whether the last of them was served by it).  Synchronises."""
+        n, last = C.c_uint64(), C.c_int32()
+        N.check(N.lib().eg_replay_hoist_stats(self.h, C.byref(n), C.byref(last)), "eg_replay_hoist_stats")
+        return int(n.value), bool(last.value)
+
     def pull(self, weights: ActionWeights):
         N.check(N.lib().eg_policy_pull(self.h, weights.h), "eg_policy_pull")
 

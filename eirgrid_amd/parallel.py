@@ -2,7 +2,7 @@
 
 Episodes are independent given a policy snapshot, so a batch is sharded by global episode index with no data-path
 collective.  The only exchange is the per-update one of SURVEY.md §8(e):
-  * device-resident policy (BatchTrainer's default under RCCL): ONE all-gather of every rank's 32 KB update packet
+  * device-resident policy (BatchTrainer's default under RCCL): ONE all-gather of every rank's 37 008-byte update packet (N.PACKET_BYTES)
     (int64 statistics + the rank's best-candidate record); k_apply_update on every rank adds the statistics (integers:
     the sum is the all-reduce) and picks the winning candidate — no host synchronisation in the step;
   * host-side policy (gloo rehearsals, exchange_packet_raw / exchange_update): a sum all-reduce of the statistics and an
@@ -13,6 +13,10 @@ replicas, no weight broadcast).  torch is used for device memory, the stream and
 from __future__ import annotations
 
 import numpy as np
+# torch is imported HERE, not lazily: the torch wheel brings its own HIP runtime, and a process that has already initialised the
+# system's one through libeirgrid_hip.so (an Engine created before the first `import torch`) finds "No HIP GPUs" in torch's —
+# measured on the GPU box.  Importing this module before creating an Engine puts torch's runtime first, where both share it.
+import torch  # noqa: F401
 
 from . import _native as N
 from .engine import ActionWeights, Engine, apply_packet, apply_reduced
@@ -208,7 +212,7 @@ class BatchTrainer:
                 self.eng.device_step(self.seed, first, self.n, self.replay_period, noise)
             else:
                 self.eng.device_rollout(self.seed, first, self.n, self.replay_period, self.packet.data_ptr())
-                # the one collective of the update (RCCL over xGMI): every rank receives every rank's 32 KB packet; the
+                # the one collective of the update (RCCL over xGMI): every rank receives every rank's 37 008-byte packet (N.PACKET_BYTES); the
                 # statistics are integers, so summing them inside k_apply_update is the all-reduce
                 if self.dist.get_backend() == "gloo":      # rehearsal without RCCL: the same exchange through the host
                     mine = self.packet.cpu()

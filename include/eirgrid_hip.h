@@ -185,7 +185,8 @@ int32_t eg_timing_read(eg_ctx *, double *total_ms, int32_t *n_launches);
  * *grids_ms = the replay grids' and the lean grid's own durations added up.  Grids that run side by side: span well below the
  * sum; grids that were serialised (e.g. two streams sharing one hardware queue): span == sum. */
 int32_t eg_timing_read_grids(eg_ctx *, double *span_ms, double *grids_ms, int32_t *n_launches);
-/* Device memory the context holds beyond the 50 KB policy: the world's tables (27 MB), the episode records (one of 41.6 KB per
+/* Device memory the context holds beyond the 50 KB policy: the world's tables (tab::total, 42 MB: 26 MB of sorted candidate lists, 11.5 MB their compact form, 3.3 MB
+ * the per-cell placement prefix the hoisted replay reads), the episode records (one of 41.6 KB per
  * episode of the largest batch so far) and the penalty-field pool of long replay episodes — 126 KB per replay episode of a launch,
  * allocated with the first replay launch unless the host knows the best list to be short (<= 96 actions: it uploaded, rewound or
  * pulled it and no on-device update is in flight), grown to the largest launch since, never beyond
@@ -324,6 +325,18 @@ int32_t eg_policy_pull(eg_ctx *, eg_policy *);
  * changes what a replay episode costs, differently for every global batch size. */
 int32_t eg_policy_hold(eg_ctx *);
 int32_t eg_policy_rewind(eg_ctx *);
+/* Replay hoist (no counterpart in the reference — it runs every iteration on its own, core/multi_simulation.rs:425-472).  An episode
+ * with replay_best_strategy = true takes every action from the stored lists and reads no seeded draw until a list runs out
+ * (ai/learning/weights/sampling.rs:78-101, :242-266; core/simulation.rs:146-162), so all replay episodes of a batch are one and the
+ * same computation.  With the hoist on (eg_replay_hoist(ctx, 1), or EIRGRID_REPLAY_HOIST=1 in the environment at eg_create; off by
+ * default) a batch computes that script ONCE — a cooperative sixteen-wave workgroup, csrc/eg_replay_coop.h — and hands every replay
+ * episode of the batch a copy of the record; records, statistics and update packets are those of the per-episode path, byte for byte
+ * (n_chunks excepted: it counts what the search that really ran requested).  A script that needs a fallback draw
+ * (sampling.rs:445-528) or would end with a status other than EG_EP_OK is not hoisted: the per-episode kernels run those episodes as
+ * before.  eg_replay_hoist_stats waits for the device: *batches_armed = batches launched with the hoist on and replay episodes in
+ * them, *last_batch_hoisted = 1 when the last such batch was served by the hoist. */
+int32_t eg_replay_hoist(eg_ctx *, int32_t on);
+int32_t eg_replay_hoist_stats(eg_ctx *, uint64_t *batches_armed, int32_t *last_batch_hoisted);
 /* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */

@@ -90,7 +90,7 @@ def test_config5_100k_iterations_checkpoint_and_resume(built, tmp_path):
 
 def test_config4_131072_episodes_as_eight_shards(world):
     """One update from 131 072 episodes: 8 shards of 16 384 by global episode index (every 10th index replays the best
-    strategy), each rolled out into its own 32 KB packet, ONE k_apply_update over the 8 packets — against the host
+    strategy), each rolled out into its own 37 008-byte packet, ONE k_apply_update over the 8 packets — against the host
     update from the same packets (statistics summed as the all-reduce would) and, for sampled episodes of every shard,
     the tabled oracle run from the global index alone (shard invariance)."""
     tb = O.OracleTables(HostTables(world), len(world.existing_x))

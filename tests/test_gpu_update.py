@@ -350,6 +350,43 @@ def test_hold_and_rewind_put_the_device_policy_back(world):
         dev.close()
 
 
+def test_rewind_behind_unpulled_updates_still_runs_the_long_replays(world):
+    """eg_policy_hold behind on-device updates that nobody has pulled, then eg_policy_rewind and a step — the host
+    does not know the held list, so BOTH replay variants must be launched (the long one used to be skipped: the replay episodes'
+    records kept the previous batch's bytes and still fed the update).  The device-resident loop grows a best list beyond 96
+    actions; after hold / rewind / step WITHOUT a pull every replay episode of the batch must be the tabled oracle's."""
+    from eirgrid_amd.engine import Engine, HostTables
+    from oracle import api as O
+    from tests.helpers import assert_episode_equal, oracle_weights_like
+    dev = Engine(world, device=0)
+    try:
+        pol = ActionWeights()
+        first = dev.run_iteration(0, pol, False, 12345)
+        pol.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0],
+                          first.def_log[0, :first.n_def[0].sum()])
+        dev.push(pol)
+        n, period = 4096, 10
+        for k in range(12):      # replay episodes win and double the replayed list (SURVEY Q15)
+            dev.device_step(12345, k * n, n, period, 900 + k)
+        dev.hold()               # ... and nobody has pulled: the host's idea of the list is the pushed one (28 actions)
+        dev.device_step(12345, 50 * n, n, period, 1000)      # something else in the records
+        dev.rewind()
+        dev.device_step(12345, 60 * n, n, period, 1001)
+        res = dev.fetch(n)
+        probe = ActionWeights()
+        dev.rewind(); dev.pull(probe)      # the held policy, for the oracle (after the batch under test)
+        assert sum(len(l) for l in probe.lists(0)) > 96, "the loop was meant to grow a long best list"
+        tb = O.OracleTables(HostTables(world), len(world.existing_x))
+        idx = np.arange(60 * n, 61 * n)
+        reps = np.flatnonzero(idx % period == 0)
+        assert (res.status == 0).all()
+        for e in list(reps[:3]) + [int(reps[-1]), 1]:
+            st, ref = O.run_episode_tabled(tb, oracle_weights_like(probe), 12345 + 60 * n + int(e), replay=bool(idx[e] % period == 0))
+            assert_episode_equal(res, int(e), ref, "after hold / rewind without a pull")
+    finally:
+        dev.close()
+
+
 def test_rccl_path_of_the_trainer_on_one_rank():
     """The N > 1 device-resident step (eg_device_rollout -> all_reduce -> all_gather_into_tensor -> eg_device_apply, all
     on the stream) with the collectives really issued through RCCL (world size 1, forced) == the single-GPU step."""
@@ -525,7 +562,7 @@ def test_best_run_record_follows_the_best_episode(engine, world, tmp_path):
 
 def test_device_resident_replicas_of_two_processes_stay_identical(tmp_path):
     """Two processes (two ranks sharing cuda:0, gloo standing in for RCCL) run the device-resident multi-rank step —
-    eg_device_rollout of the own shard, exchange of the 32 KB packets, eg_device_apply on both packets — and the
+    eg_device_rollout of the own shard, exchange of the 37 008-byte packets, eg_device_apply on both packets — and the
     host-driven step on the same shards: after 8 steps all four policies must be the same, bit for bit."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
