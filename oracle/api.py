@@ -134,12 +134,28 @@ def lib():
     L.og_detpow.argtypes = [C.c_double, C.c_double]
     L.og_libm_pow.restype = C.c_double
     L.og_libm_pow.argtypes = [C.c_double, C.c_double]
+    L.og_set_libm_pow.argtypes = [C.c_int32]
+    L.og_get_libm_pow.restype = C.c_int32
     _lib = L
     return L
 
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class libm_pow:
+    """Context manager: inside it the oracle's stalled sampler (sampling.rs:199-213) calls libm's pow, as the reference's f64::powf
+    does, instead of the shared eg_detpow (oracle/eg_oracle.c og_set_libm_pow)."""
+
+    def __enter__(self):
+        self.before = lib().og_get_libm_pow()
+        lib().og_set_libm_pow(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().og_set_libm_pow(self.before)
+        return False
 
 
 class OracleWorld:

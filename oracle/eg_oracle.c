@@ -17,6 +17,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* The stalled sampler's w.powf(p) (sampling.rs:199-213).  Default: the shared IEEE-only eg_detpow, which the kernels evaluate too —
+ * so that oracle and kernel agree to the bit by construction.  og_set_libm_pow(1) makes the oracle do what the reference does: call
+ * libm's pow.  That mode is what breaks the circle of comparing eg_detpow with itself: the product (eg_detpow on the device) is then
+ * held against an oracle that never sees that function (tests/test_detpow.py, tests/test_gpu_parity.py). */
+static int g_libm_pow = 0;
+void og_set_libm_pow(int32_t on) { g_libm_pow = on ? 1 : 0; }
+int32_t og_get_libm_pow(void) { return g_libm_pow; }
+static double stalled_pow(double x, double p) { return g_libm_pow ? pow(x, p) : eg_detpow(x, p); }
+
 /* ------------------------------------------------------------------------- */
 /* constants (config/constants.rs, ai/learning/constants.rs)                  */
 /* ------------------------------------------------------------------------- */
@@ -906,14 +915,15 @@ static int sample_action(og_weights *p, int yi) { /* sampling.rs:76-238 */
   double total_weight = 0.0; for (int a = 0; a < OG_NA; ++a) total_weight += yw[a];
   if (total_weight <= 0.0) return 3 * T_PEAKER;
   if (p->stall > 500) { /* power-scaled selection (sampling.rs:190-220), stable sort by weight descending; powf is
-                         * evaluated by the shared eg_detpow (include/eg_detpow.h), < 2e-14 relative from libm's pow */
+                         * evaluated by the shared eg_detpow (include/eg_detpow.h), < 2e-14 relative from libm's pow — or, in the
+                         * literal-libm mode (og_set_libm_pow), by libm's pow itself, as the reference does */
     int order[OG_NA]; for (int a = 0; a < OG_NA; ++a) order[a] = a;
     for (int i = 1; i < OG_NA; ++i) { int k = order[i], j = i - 1; while (j >= 0 && yw[order[j]] < yw[k]) { order[j + 1] = order[j]; --j; } order[j + 1] = k; }
     double stagnation_factor = mind((double)p->stall / 1000.0, 3.0);
     double power_scaling = 1.0 + (2.0 * stagnation_factor);
-    double total_scaled = 0.0; for (int i = 0; i < OG_NA; ++i) total_scaled += eg_detpow(yw[order[i]], power_scaling);
+    double total_scaled = 0.0; for (int i = 0; i < OG_NA; ++i) total_scaled += stalled_pow(yw[order[i]], power_scaling);
     double random_val = rng_f64(&p->rng) * total_scaled;
-    for (int i = 0; i < OG_NA; ++i) { random_val -= eg_detpow(yw[order[i]], power_scaling); if (random_val <= 0.0) return order[i]; }
+    for (int i = 0; i < OG_NA; ++i) { random_val -= stalled_pow(yw[order[i]], power_scaling); if (random_val <= 0.0) return order[i]; }
     return order[0];
   }
   double random_val = rng_f64(&p->rng) * total_weight;

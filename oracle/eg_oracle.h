@@ -178,6 +178,10 @@ void og_rng_stream(uint64_t seed, int32_t n, uint64_t *out_u64);    /* first n n
 uint64_t og_rng_gen_range_probe(uint64_t seed, uint64_t n, int32_t skip); /* gen_range(0..n) after `skip` u64 draws */
 double og_detpow(double x, double p);   /* include/eg_detpow.h as compiled into the oracle */
 double og_libm_pow(double x, double p);
+/* 1: the stalled sampler (sampling.rs:199-213) raises its weights with libm's pow, as the reference's f64::powf does; 0 (default):
+ * with the shared eg_detpow the kernels evaluate.  Process-wide. */
+void og_set_libm_pow(int32_t on);
+int32_t og_get_libm_pow(void);
 
 #ifdef __cplusplus
 }

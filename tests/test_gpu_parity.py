@@ -105,6 +105,23 @@ def test_snapshot_variants(engine, world):
             assert_episode_equal(res, e, ref, f"variant {k}")
 
 
+def test_stalled_sampler_against_the_oracle_with_libm_pow(engine, world):
+    """stall > 500: the reference's sampler raises the sorted weights with f64::powf (sampling.rs:199-213).  The kernels evaluate the
+    shared eg_detpow (IEEE basic operations only) — and so does the oracle by default, which made the bitwise claim for this branch a
+    comparison of that function with itself.  Here the oracle calls libm's pow, as the reference does (og_set_libm_pow): the
+    product's episodes at stall 501 / 900 / 1500 / 3500 must still be the oracle's, every action index and every float.  (A pick can
+    only differ when a draw lands within 2e-14 of a boundary of the powered table; none does in these 4 x 48 episodes.)"""
+    tb = _tabled(world)
+    for k, stall in enumerate((501, 900, 1500, 3500)):
+        pol = ActionWeights(); pol.set("iterations_without_improvement", stall)
+        res = engine.rollout_batch(pol, 4242 + k, 48)
+        with O.libm_pow():
+            for e in range(48):
+                st, ref = O.run_episode_tabled(tb, oracle_weights_like(pol), 4242 + k + e)
+                assert_episode_equal(res, e, ref, f"stall {stall}, oracle with libm pow")
+        assert O.lib().og_get_libm_pow() == 0
+
+
 def test_energy_sales_off(engine, world):
     tb = _tabled(world)
     res = engine.rollout_batch(ActionWeights(), 99, 8, enable_energy_sales=False)

@@ -79,3 +79,73 @@ def test_readme_generation_2025(built, tmp_path):
     st, es = O.run_episode(ow, O.OracleWeights(), 12345)
     own = sum(O.lib().og_type_power_output(int(t)) for t, y in zip(es.gen_type[:es.n_gens], es.gen_year[:es.n_gens]) if y == 0)
     assert st == 0 and "%.2f" % (es.yearly[0][3] - own) == GOLD["existing_generation_mw"]
+
+
+ACTION_INDEX = {"OnshoreWind": 0, "OffshoreWind": 3, "DomesticSolar": 6, "CommercialSolar": 9, "UtilitySolar": 12, "BatteryStorage": 36,
+                "WaveEnergy": 42, "Forest": 45}      # canonical action index at the 100 % multiplier (include/eirgrid_hip.h)
+
+
+def _replay_policy(actions):
+    """An oracle ActionWeights whose best strategy is the README's Actions table, so that a replay applies every listed action
+    exactly once.  With the existing plant online the README's generation exceeds its usage at the start of every year but one: 2049
+    starts at 15 386.15 MW against 15 774.02 MW of demand (README.md:119-120), so the repair loop runs there (simulation.rs:137-141)
+    and places the first of that year's three batteries from the deficit list — the other two follow as additional actions."""
+    pol = O.OracleWeights()
+    pol.set("has_best", 1); pol.set("has_best_actions", 1); pol.set("has_best_deficit_actions", 1)
+    per_year = {}
+    for year, kind, count in actions:
+        per_year.setdefault(year, []).extend([ACTION_INDEX[kind]] * count)
+    assert per_year[2049] == [ACTION_INDEX["BatteryStorage"]] * 3
+    per_year[2049] = per_year[2049][1:]
+    pol.set_list(1, 2049 - 2025, [ACTION_INDEX["BatteryStorage"]])
+    for year, lst in per_year.items():
+        pol.set_list(0, year - 2025, lst)
+    return pol
+
+
+def test_readme_action_table_reproduces_the_generation_column(built, tmp_path):
+    """README.md:64-91 (the published run's actions: year, type, count) replayed on the reference's own ireland_generators.csv through
+    apply_action -> add_generator -> calc_total_power_generation (core/actions.rs:42-91, utils/map_handler.rs:829-868,
+    models/generator.rs:523-554), against README.md:96-121's Power Generation column:
+      * 2025-2038: the column itself, cumulatively, to the printed digits (14 rows);
+      * 2040-2047: the year-on-year rise (2040 +495.00 = Battery; 2042 +281.16 = 2 x 1.98 + 277.2; 2044 +1108.80);
+      * 2039 is the README's own inconsistency: its table says Offshore Wind x8 + Onshore Wind x1, its column rises by one more
+        Offshore Wind (277.20 MW) — with that one plant added the WHOLE column is reproduced cumulatively, all 26 rows (2048 +1.98,
+        2049 +1485.00 = 3 x 495, 2050 +435.60 = 2 x 99 + 4 x 59.4 included).
+    Seven of the fifteen per-type outputs (Onshore / Offshore Wind, Domestic / Commercial / Utility Solar, Battery, Wave) are pinned by
+    it.  Literal oracle, tabled oracle on the product's host tables (bit-identical to each other), the README's own numbers."""
+    from decimal import Decimal
+    from eirgrid_amd.engine import HostTables
+    _, world = _reference_world(tmp_path, True)
+    ow = O.OracleWorld(world)
+    tb = O.OracleTables(HostTables(world), len(world.existing_x))
+    col = {int(y): Decimal(v) for y, v in GOLD["power_generation_mw"].items()}
+    bad = GOLD["readme_inconsistency"]
+
+    def generation(actions, whole):
+        pol = _replay_policy(actions)
+        st, ep = O.run_episode(ow, pol.clone(), 12345, replay=True)
+        st2, et = O.run_episode_tabled(tb, pol.clone(), 12345, replay=True)
+        assert st == 0 and st2 == 0 and np.array(ep.yearly).tobytes() == np.array(et.yearly).tobytes()
+        last = 26 if whole else 2048 - 2025      # (the table as printed runs into a deficit in 2048 — see below)
+        assert [int(c) for c in ep.n_def][:last] == ([0] * 24 + [2, 0])[:last]
+        assert [int(c) for c in ep.n_act][:last] == [sum(c for y, _, c in actions if y == 2025 + i) - (1 if i == 24 else 0) for i in range(26)][:last]
+        if whole:      # no fallback draw; ONE repair action (2049's first battery, recorded twice by the replay, SURVEY Q15): the table, applied once
+            assert ep.n_draws == 0
+            assert ep.n_gens == sum(c for _, k, c in actions if k != "Forest") and ep.n_offsets == sum(c for _, k, c in actions if k == "Forest")
+        return [Decimal("%.2f" % ep.yearly[i][3]) for i in range(26)]      # EG_Y_GEN
+
+    # the table as printed: the column cumulatively up to 2038, the year-on-year rises after 2039 — up to 2047: short of one Offshore
+    # Wind, this run starts 2048 with 15 106.97 MW against 15 107.45 MW of demand and its repair loop adds plant the README's run never
+    # needed (the README's own column has 15 384.17 MW there)
+    gen = generation([tuple(a) for a in GOLD["actions"]], False)
+    for year in range(2025, 2039):
+        assert gen[year - 2025] == col[year], (year, gen[year - 2025], col[year])
+    for year in range(2040, 2048):
+        assert gen[year - 2025] - gen[year - 2026] == col[year] - col[year - 1], year
+    assert (col[2039] - col[2038]) - (gen[14] - gen[13]) == Decimal(bad["missing_mw"]) and bad["year"] == 2039
+    assert "%.2f" % O.lib().og_type_power_output(1) == bad["missing_mw"]      # exactly one Offshore Wind
+    assert gen[2047 - 2025] < Decimal("15107.45") < col[2047]                 # ... which is what keeps 2048 out of deficit in the README
+    # with that plant: the WHOLE column, cumulatively, all 26 rows (2048 +1.98, 2049 +1485.00, 2050 +435.60 included)
+    fixed = generation([tuple(a) for a in GOLD["actions"]] + [(2039, bad["type"], 1)], True)
+    assert fixed == [col[y] for y in range(2025, 2051)]
