@@ -108,7 +108,7 @@ struct eg_ctx {
   // d_hoist: {u64 sequence number of the last batch whose hoist succeeded, i32 lengths[5]}; d_coop: the scratch record.
   bool hoist_on = false, hoist_supported = false;
   unsigned long long hoist_seq = 0;
-  unsigned long long* d_hoist = nullptr; uint8_t* d_coop = nullptr;
+  HoistInfo* d_hoist = nullptr; uint8_t* d_coop = nullptr;
   uint64_t hoist_batches = 0;      // batches launched with the hoist armed (eg_replay_hoist_stats)
 };
 
@@ -350,6 +350,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     const int NV = int(variants.size());
     if (NV > kMaxVariants) { set_error("eg_create: too many (radius class, marine) variants"); rc = EG_ERR_BAD_ARG; }
     put(blob, tab::variant, variant_of, kTypes);
+    D.n_variants = NV;
     PsRec* ps = reinterpret_cast<PsRec*>(blob.data() + tab::ps);   // entries beyond the 2601 candidates stay te = 0
     std::vector<double> base(kCells);
     std::vector<int> order(kCells);
@@ -364,6 +365,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
         double* pb = reinterpret_cast<double*>(blob.data() + tab::pbase) + (size_t(y) * kMaxVariants + v) * kPcStride;
         uint32_t* pc = reinterpret_cast<uint32_t*>(blob.data() + tab::pcell) + (size_t(y) * kMaxVariants + v) * kPcStride;
         for (int r = 0; r < kPcStride; ++r) { pb[r] = r < kCells ? base[order[r]] : 0.0; pc[r] = r < kCells ? uint32_t(order[r]) : 0u; }
+        std::memcpy(blob.data() + tab::cbase + 8 * (size_t(y) * kMaxVariants + v) * kCells, base.data(), 8 * size_t(kCells));      // the same scores per cell
         for (int r = 0; r < kCells; ++r) {
           list[r].te = te[order[r]]; list[r].cf = marine ? H.coastf[order[r]] : 1.0; list[r].m03 = H.m03[order[r]]; list[r].cell = uint32_t(order[r]);
           list[r].pad = uint32_t(4 * (order[r] / kGrid)) | (uint32_t(4 * (order[r] % kGrid)) << 16);
@@ -408,7 +410,8 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
           ++nbox;
         }
     if (nbox > 1024) c->heavy_slots_wanted = 0;      // radii the list was not sized for: heavy episodes keep the exact scan
-    c->hoist_supported = nbox <= 1024;                // (the hoisted replay updates its field with one lane per entry of this list)
+    // (the hoisted replay updates its field with one lane per entry of this list and keeps the scores of eight variants in registers)
+    c->hoist_supported = nbox <= 1024 && D.n_variants <= 8;
     for (int i = nbox; i < 1024; ++i) box[i] = 145u << 10;      // padding: class 0, di = dj = -16 (no class reaches that far), q = 145 (factor 1.0)
     for (int k = 0, i = 0; k <= kRadiusClasses; ++k) {      // words 1024..1030: where class k starts (the list is sorted by class), then the end
       while (i < nbox && i < 1024 && int(box[i] >> 19) < k) ++i;
@@ -475,8 +478,8 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     } else { (void)hipGetLastError(); c->h_list_len = nullptr; }
   }
   if (rc == EG_OK) {
-    if (hipMalloc((void**)&c->d_hoist, kHoistBytes) != hipSuccess || hipMalloc((void**)&c->d_coop, rec::stride) != hipSuccess ||
-        hipMemset(c->d_hoist, 0, kHoistBytes) != hipSuccess || hipMemset(c->d_coop, 0, rec::stride) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_hoist, kHoistBytes) != hipSuccess || hipMalloc((void**)&c->d_coop, rec::stride + 64) != hipSuccess ||
+        hipMemset(c->d_hoist, 0, kHoistBytes) != hipSuccess || hipMemset(c->d_coop, 0, rec::stride + 64) != hipSuccess) {
       set_error("hipMalloc(replay hoist) failed"); rc = EG_ERR_HIP;
     }
     if (const char* rh = std::getenv("EIRGRID_REPLAY_HOIST")) c->hoist_on = c->hoist_supported && rh[0] == '1';
@@ -875,7 +878,7 @@ int device_apply(eg_ctx* c, const void* d_packets, int32_t n_packets, void* d_ow
 
 int32_t eg_replay_hoist(eg_ctx* c, int32_t on) {
   if (!c) { set_error("eg_replay_hoist: bad argument"); return EG_ERR_BAD_ARG; }
-  if (on && !c->hoist_supported) { set_error("eg_replay_hoist: this world's penalty radii exceed the field-update list (no hoist)"); return EG_ERR_UNSUPPORTED; }
+  if (on && !c->hoist_supported) { set_error("eg_replay_hoist: this world's penalty radii / type variants exceed what the hoisted replay is sized for"); return EG_ERR_UNSUPPORTED; }
   c->hoist_on = on != 0;
   return EG_OK;
 }
@@ -887,7 +890,16 @@ int32_t eg_replay_hoist_stats(eg_ctx* c, uint64_t* batches_armed, int32_t* last_
   unsigned long long word = 0;
   EG_HIP(hipMemcpy(&word, c->d_hoist, sizeof(word), hipMemcpyDeviceToHost));
   if (batches_armed) *batches_armed = c->hoist_batches;
+  static_assert(offsetof(HoistInfo, served_seq) == 0, "the served word comes first");
   if (last_batch_hoisted) *last_batch_hoisted = (c->hoist_seq != 0ull && word == c->hoist_seq) ? 1 : 0;
+  return EG_OK;
+}
+
+int32_t eg_debug_hoist_stamps(eg_ctx* c, uint64_t stamps[8]) {
+  if (!c || !stamps) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  EG_HIP(hipDeviceSynchronize());
+  EG_HIP(hipMemcpy(stamps, reinterpret_cast<const uint8_t*>(c->d_hoist) + offsetof(HoistInfo, stamps), 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return EG_OK;
 }
 

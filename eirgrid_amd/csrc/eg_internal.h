@@ -120,13 +120,17 @@ constexpr size_t hv_quads = a16(hv_lists + 4 * size_t(64) * 1024);              
 // every cell of the grid at once, so it wants the candidates in cell order, not sorted
 constexpr size_t te_cell = a16(hv_quads + 4 * 64);                                          // f64 [26][6][2601]
 constexpr size_t coastf = a16(te_cell + 8 * size_t(kYears) * kRadiusClasses * kCells);      // f64 [2601]
-constexpr size_t total = a16(coastf + 8 * size_t(kCells));
+// ... and the unpenalised score (te * cf) * size_factor of every (year, variant) per cell — tab::pbase in cell order: what the hoisted
+// replay's searches multiply the penalty field with (te_cell / coastf: the exact evaluation of tied candidates)
+constexpr size_t cbase = a16(coastf + 8 * size_t(kCells));                                  // f64 [26][kMaxVariants][2601]
+constexpr size_t total = a16(cbase + 8 * size_t(kYears) * kMaxVariants * kCells);
 }  // namespace tab
 
 struct DevTables {
   const uint8_t* base;
   double size_factor;
   int32_t n_existing;
+  int32_t n_variants;      // distinct (radius class, marine) pairs among the generator types (tab::variant)
   // heavy episodes (eg_rollout.hip, place_heavy): a pool of per-episode penalty fields [6][2624] f64 in HBM, claimed per
   // launch through `heavy_claim` (launch epoch << 20 | slots handed out)
   uint32_t heavy_slots, heavy_epoch;
@@ -141,7 +145,7 @@ struct DevTables {
   EG_TAB(dr, double) EG_TAB(m03, double) EG_TAB(t12, double) EG_TAB(offv, double) EG_TAB(offc, double) EG_TAB(cc, double)
   // placement: candidates of every (year, variant) sorted by unpenalised score, descending (ties: ascending cell)
   EG_TAB(ps, PsRec) EG_TAB(pbase, double) EG_TAB(pcell, uint32_t) EG_TAB(hv_lists, uint32_t) EG_TAB(hv_quads, int32_t) EG_TAB(dr_meta, int32_t) EG_TAB(dr_compact, double)
-  EG_TAB(te_cell, double) EG_TAB(coastf, double)
+  EG_TAB(te_cell, double) EG_TAB(coastf, double) EG_TAB(cbase, double)
 #undef EG_TAB
 };
 
@@ -278,6 +282,7 @@ struct UpdateCandidate;
 // returns at once), n_lean on the lean one; on two streams side by side when both are present (stream_heavy: the library's
 // side stream, stream_lean: the null stream).  mode 1: d_index holds the n_heavy replay episodes followed by the n_lean others; mode 2: the replays are
 // off + period * j.  ev: start / stop events of the heavy and of the lean grid (only the ones launched are recorded).
+struct HoistInfo;
 struct RolloutPlan {
   bool helper_waves;
   void* stream_heavy; void* stream_lean;
@@ -292,10 +297,22 @@ struct RolloutPlan {
   // last batch whose hoist succeeded, i32 lengths[8]} — the per-episode replay variants are launched in between and return at once
   // when the word says their batch has been served
   unsigned long long hoist_seq;
-  unsigned long long* d_hoist;
+  HoistInfo* d_hoist;
   uint8_t* coop_out;
 };
-constexpr size_t kHoistBytes = 64;      // d_hoist: u64 word | i32 lengths {run, def, act, gens, offsets}
+// d_hoist (device): what the kernels of the replay hoist hand each other
+struct HoistInfo {
+  unsigned long long served_seq;      // written by k_replay_books: the batch whose replay episodes are served by the scratch record
+  unsigned long long coop_seq;        // written by k_replay_coop: the batch whose script and placements are complete in the scratch record
+  int32_t lens[6];                    // recorded run / deficit / additional actions, generators, offsets, searches beyond the one exchange
+  int32_t pad[2];
+  int32_t g_end[EG_YEARS], o_end[EG_YEARS];      // generators / offsets at the end of each year
+  unsigned long long bytes;           // algorithmic bytes of the episode (SURVEY §8(d) formula, as k_rollout counts them)
+  int32_t books_done, pad2;           // k_replay_books: workgroups (years) that have written their row
+  double year[EG_YEARS][8];           //   their yearly total cost, credit, sales; net, opinion, total capital, balance
+  unsigned long long stamps[8];       // diagnostic builds (-DEG_COOP_STAMPS): cycle counts of the phases
+};
+constexpr size_t kHoistBytes = (sizeof(HoistInfo) + 63) & ~size_t(63);
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& plan);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook

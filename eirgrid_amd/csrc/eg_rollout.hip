@@ -1542,22 +1542,25 @@ __device__ __forceinline__ void load_state(DevSnapshot& S) {
 }
 
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
-__device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats) {
+// `mult`: the episode stands for that many identical ones (the hoisted replay, eg_replay_coop.h): every sum receives mult times its
+// contribution — integers, so that IS adding it mult times.
+__device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats,
+                                     unsigned long long mult = 1ull) {
   unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
   if (*O.status(e) != EG_EP_OK) {
-    if (lane == 0) { atomicAdd(&st[1], 1ull); *O.score(e) = -1.0; O.score_list[e] = -1.0; }
+    if (lane == 0) { atomicAdd(&st[1], mult); *O.score(e) = -1.0; O.score_list[e] = -1.0; }
     return;
   }
   const double score = rm::score(O.metrics(e));
   // st[3]: the batch's best score as an integer that sorts like the score (scores are not negative; + 1 so that 0 means
   // "no successful episode"): with one GPU k_apply_update finds the best episode from it without a kernel of its own
-  if (lane == 0) { atomicAdd(&st[0], 1ull); *O.score(e) = score; O.score_list[e] = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
+  if (lane == 0) { atomicAdd(&st[0], mult); *O.score(e) = score; O.score_list[e] = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
   const bool qualifies = det > P.threshold || P.forced;                                               // learning.rs:160
   unsigned long long q_pen = 0, q_mild = 0;
   if (qualifies) {
-    if (lane == 0) atomicAdd(&st[2], 1ull);
+    if (lane == 0) atomicAdd(&st[2], mult);
     if (det < 0.0) {      // forced contrast on an episode that beats the best: powf(negative, 0.3) is NaN in the reference and
                           // (w * NaN).max(MIN_WEIGHT) == MIN_WEIGHT — in log space any exponent below -9.2 (eg_reduced_math.h)
       q_pen = q_mild = (unsigned long long)(long long)(rm::kLnNanPenalty * kQ32);
@@ -1585,6 +1588,7 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
   const int total = __builtin_amdgcn_readlane(rp, EG_YEARS - 1) + __builtin_amdgcn_readlane(dp, EG_YEARS - 1);
   rp -= nr; dp -= nd;
   const int ip = rp + dp;
+  q_pen *= mult; q_mild *= mult;      // (two's-complement products: the sum of mult equal terms)
   for (int base = 0; base < total; base += kWave) {
     const int i = base + lane;
     int y = 0;      // the year of item i: the last year that starts at or before it (empty years share their start with the next one)
@@ -1609,7 +1613,7 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
     }
     if (valid && j >= nr_y && !((dmask >> a) & 1ull)) {        // learning.rs:346-352
       const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
-      if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], 1ull);
+      if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], mult);
     }
   }
 }
@@ -2800,17 +2804,19 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     else { m.mode = 2u; m.off = p.off; m.period = p.period; }
     const bool hoist = p.hoist_seq != 0ull;
     if (hoist) {
-      // Replay hoist: ONE workgroup computes the batch's replay script (k_replay_coop, sixteen waves and the whole LDS of a CU — it must
-      // be dispatched BEFORE the lean grid fills every CU: the lean grid's stream waits for an event recorded right in front of it),
-      // the per-episode variants follow and return at once when it has succeeded, k_replay_broadcast hands out the record.
-      m.hoist = p.d_hoist; m.hoist_seq = p.hoist_seq;
+      // Replay hoist: ONE workgroup computes the batch's replay script and its placements (k_replay_coop, four waves with the whole
+      // register file and LDS of a CU — it must be dispatched BEFORE the lean grid fills every CU: the lean grid's stream waits for an
+      // event recorded right in front of it), k_replay_books the yearly rows; the per-episode variants follow and return at once when
+      // that has succeeded, k_replay_broadcast hands out the record.
+      m.hoist = reinterpret_cast<const unsigned long long*>(p.d_hoist); m.hoist_seq = p.hoist_seq;      // (HoistInfo::served_seq comes first)
       if (p.go_event && p.n_lean > 0) {
         (void)hipEventRecord((hipEvent_t)p.go_event, (hipStream_t)p.stream_heavy);
         (void)hipStreamWaitEvent((hipStream_t)p.stream_lean, (hipEvent_t)p.go_event, 0);
       }
-      const DevOut scratch{p.coop_out, nullptr};
+      const DevOut scratch{p.coop_out, reinterpret_cast<double*>(p.coop_out + rec::stride)};
       hipExtLaunchKernelGGL(k_replay_coop, dim3(1), dim3(coop::kThreads), 0, (hipStream_t)p.stream_heavy, (hipEvent_t)p.ev[0], nullptr, 0,
                             t, s, scratch, p.hoist_seq, p.d_hoist);
+      hipLaunchKernelGGL(k_replay_books, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)p.stream_heavy, t, s, scratch, p.hoist_seq, p.d_hoist, d_stats, p.n_heavy);
     }
     // (the short one first: when it is the one that returns at once it finds the chip empty and is gone in microseconds; a
     //  256-register wave of the long one, when IT has nothing to do, must wait until a SIMD full of lean waves has drained two
@@ -2824,9 +2830,9 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     if (!p.skip_long) launch_variant<kReplayLong>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_heavy, nullptr, hoist ? nullptr : p.ev[1]);
     else if (!hoist) (void)hipEventRecord((hipEvent_t)p.ev[1], (hipStream_t)p.stream_heavy);
     if (hoist) {
-      const DevOut scratch{p.coop_out, nullptr};
+      const DevOut scratch{p.coop_out, reinterpret_cast<double*>(p.coop_out + rec::stride)};
       hipExtLaunchKernelGGL(k_replay_broadcast, dim3(m.count), dim3(kWave), 0, (hipStream_t)p.stream_heavy, nullptr, (hipEvent_t)p.ev[1], 0,
-                            s, scratch, o, n, d_stats, m, (const unsigned long long*)p.d_hoist, p.hoist_seq);
+                            s, scratch, o, n, d_stats != nullptr ? 1 : 0, m, (const HoistInfo*)p.d_hoist, p.hoist_seq);
     }
   }
   if (p.n_lean > 0) {

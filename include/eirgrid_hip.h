@@ -337,6 +337,9 @@ int32_t eg_policy_rewind(eg_ctx *);
  * them, *last_batch_hoisted = 1 when the last such batch was served by the hoist. */
 int32_t eg_replay_hoist(eg_ctx *, int32_t on);
 int32_t eg_replay_hoist_stats(eg_ctx *, uint64_t *batches_armed, int32_t *last_batch_hoisted);
+/* Diagnostic hook: cycle counts of the hoisted script's phases as a -DEG_COOP_STAMPS build of the library leaves them (zeros in the
+ * shipped build): between commands, year start (own chains), waiting for the other waves' chains, command barrier, search, field update. */
+int32_t eg_debug_hoist_stamps(eg_ctx *, uint64_t stamps[8]);
 /* Checkpoints in the reference's JSON schema (SerializableWeights, ai/learning/serialization.rs:38-51):
  * save_to_file / load_from_file of ai/learning/weights/serialization.rs:29-493.  As in the reference the count table
  * is not part of the file; a loaded policy samples the action count with the heuristic branch (sampling.rs:423-442). */
