@@ -20,7 +20,7 @@
 //      the product of the penalty factors of every generator placed so far is kept per radius class and cell in LDS (field[6][2624]
 //      f64, 126 KB of the CU's 160 KB; updated for the new generator by one lane per (class, di, dj) entry of the host's list), the
 //      year's unpenalised scores (tab::cbase) sit in registers, so approx(c) = base(c) * field[c] is a read and a multiplication per
-//      cell.  One exchange through LDS gives the largest approximate score and says whether a second cell comes within 2^-20 of it.
+//      cell.  One exchange through LDS gives the largest approximate score and says whether a second cell comes within 2^-16 of it.
 //      If none does — the usual case — the holder IS the reference's arg-max (exact and approximate score are the same real product
 //      rounded at most G + 3 times each: they differ by less than 2^-40 relative for the 4 096 generators a list can hold) and only
 //      its cell is asked for.  Otherwise every cell within 2^-30 of the exact maximum of the approximate scores is evaluated EXACTLY
@@ -59,7 +59,7 @@ struct __align__(16) Smem {
   uint16_t gcell[EG_MAX_GENS];                      // the episode's generators: cell (phase 2)
   uint16_t gpack[EG_MAX_GENS];                      //   type | build-year index << 4 | multiplier index << 9 (the record's gen_pack; phase 1)
   uint16_t opack[EG_MAX_OFFSETS];                   // the episode's offsets (the record's off_pack; phase 1)
-  struct { uint32_t top1, top2; int cell, pad; } top[kWaves];      // a search's exchange: high words of each wave's two largest approximate scores
+  struct __align__(16) { uint32_t top1, top2; int cell, pad; } top[kWaves];      // a search's exchange: high words of each wave's two largest approximate scores
   int n_gens, failed;                               // phase 1 -> phase 2
   double xscore[kWaves]; int xcell[kWaves]; int xcnt[kWaves];      // slow paths: per-wave maxima / candidate counts
   int cand[kWave]; double cand_score[kWave];
@@ -68,6 +68,19 @@ static_assert(sizeof(Smem) <= 160 * 1024, "one workgroup owns the CU's LDS");
 __shared__ Smem sc;
 // Every barrier of this kernel orders LDS only (wg_barrier_lds: s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also wait for
 // the wave's outstanding global stores and loads.
+
+#ifdef EG_COOP_STAMPS      // diagnostic build (make ab AB=coopstamps ABFLAGS=-DEG_COOP_STAMPS; scripts/coop_stamps.py)
+#define EG_CS(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); cs[slot] += now_ - cs_last; cs_last = now_; } while (0)
+#else
+#define EG_CS(slot) do {} while (0)
+#endif
+#ifdef EG_COOP_STAMPS
+#define EG_CS_ARGS , unsigned long long* cs, unsigned long long& cs_last
+#define EG_CS_PASS , cs, cs_last
+#else
+#define EG_CS_ARGS
+#define EG_CS_PASS
+#endif
 
 // v_max_f64 / v_min_f64 as such (from a > b ? a : b the compiler makes a compare and two selects; the values here are never NaN)
 __device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -101,39 +114,47 @@ __device__ __forceinline__ double exact_chain(int off, int cap, int ngen, double
 // ---- a search, fast path: this lane's cells against the field, the exchange, the decision.  `b`: the lane's unpenalised scores of the
 //      (year, variant) — registers; returns the winning cell, or -2: several cells within reach of the maximum / nothing placeable (the
 //      caller takes the slow path).  Called by all four waves; every lane returns the same value. ----
-__device__ __forceinline__ int scan_fast(const double (&b)[kPer], int rc, int tid, int lane, int wave) {
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int scan_fast(const double (&b)[kPer], int rc, int tid, int lane, int wave EG_CS_ARGS) {
   const char* f0 = reinterpret_cast<const char*>(sc.field) + (rc * kFieldStride + tid) * 8;
-  // the lane's largest and second largest approximate score; the cell slot k rides in the four lowest bits of the value (2^-48
-  // relative: the decision below looks at high words only), so that one v_max keeps value and place
-  double l1 = 0.0, l2 = 0.0;
+  // The lane's largest and second largest approximate score, as 32-bit keys: the score's high word (scores are not negative: ordered
+  // like their bit patterns) with the cell slot k in its four lowest bits — a key bounds its score within 2^-16, which is all the
+  // decision below needs, and a v_max / v_med3 pair per cell keeps value, place and runner-up (l1 >= l2 throughout, so the median of
+  // {l1, l2, key} is the new runner-up).
+  uint32_t l1 = 0u, l2 = 0u;
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     // (the last slot reaches beyond the grid for most lanes: their score there is 0 and the read is bent to the class's padding)
     const double f = k + 1 < kPer ? *reinterpret_cast<const double*>(f0 + k * kThreads * 8)
                                   : sc.field[rc * kFieldStride + (tid + k * kThreads < kFieldStride ? tid + k * kThreads : kFieldStride - 1)];
     const double a = b[k] * f;
-    const double key = __hiloint2double(__double2hiint(a), (__double2loint(a) & ~15) | k);
-    l2 = vmax(l2, vmin(l1, key));
-    l1 = vmax(l1, key);
+    const uint32_t key = ((uint32_t)__double2hiint(a) & ~15u) | (uint32_t)k;
+    l2 = med3_u32(l1, l2, key);
+    l1 = l1 > key ? l1 : key;
   }
-  const int lcell = tid + (__double2loint(l1) & 15) * kThreads;
-  const uint32_t h1 = (uint32_t)__double2hiint(l1), h2 = (uint32_t)__double2hiint(l2);
-  const uint32_t w1 = wave_max_u32(h1);
-  const unsigned long long hold = __ballot(h1 == w1);
-  uint32_t w2 = wave_max_u32(h1 == w1 ? h2 : h1);
+  EG_CS(3);      // 3: searches: the lane's cells
+  const int lcell = tid + (int)(l1 & 15u) * kThreads;
+  const uint32_t w1 = wave_max_u32(l1);
+  const unsigned long long hold = __ballot(l1 == w1);
+  uint32_t w2 = wave_max_u32(l1 == w1 ? l2 : l1);
   if (__popcll(hold) > 1) w2 = w1;
   const int wcell = __builtin_amdgcn_readlane(lcell, __ffsll((long long)hold) - 1);
   if (lane == 0) { sc.top[wave].top1 = w1; sc.top[wave].top2 = w2; sc.top[wave].cell = wcell; }
+  EG_CS(4);      // 4: searches: the wave's two largest
   wg_barrier_lds();
-  const uint32_t r1 = lane < kWaves ? sc.top[lane].top1 : 0u, r2 = lane < kWaves ? sc.top[lane].top2 : 0u;
+  EG_CS(6);      // 6: searches: the exchange's barrier
+  // (lane w < 4 reads wave w's entry — keys and cell in ONE 16-byte read: every LDS round trip of a search is on the batch's serial path)
+  int4 tv = {0, 0, 0, 0};
+  if (lane < kWaves) tv = *reinterpret_cast<const int4*>(&sc.top[lane]);
+  const uint32_t r1 = (uint32_t)tv.x, r2 = (uint32_t)tv.y;
   const uint32_t mh = wave_max_u32(r1);
-  const double m_lo = __hiloint2double((int)mh, 0);      // a lower bound of the largest approximate score, within 2^-20
-  if (!(m_lo >= 1e-250)) return -2;                      // nothing placeable, or subnormal territory
+  const double m_lo = __hiloint2double((int)(mh & ~15u), 0);      // a lower bound of the largest approximate score, within 2^-16
+  if (!(m_lo >= 1e-250)) return -2;                                // nothing placeable, or subnormal territory
   const double thr = m_lo * kKeepCoop;
-  const unsigned long long c1 = __ballot(lane < kWaves && __hiloint2double((int)r1, -1) >= thr);
-  const unsigned long long c2 = __ballot(lane < kWaves && __hiloint2double((int)r2, -1) >= thr);
+  const unsigned long long c1 = __ballot(lane < kWaves && __hiloint2double((int)(r1 | 15u), -1) >= thr);      // (upper bounds of the scores behind the keys)
+  const unsigned long long c2 = __ballot(lane < kWaves && __hiloint2double((int)(r2 | 15u), -1) >= thr);
   // ONE candidate: it is the arg-max (the arg-max is among the candidates) and only its cell is asked for
-  if (__popcll(c1) + __popcll(c2) == 1) return sc.top[__ffsll((long long)c1) - 1].cell;
+  if (__popcll(c1) + __popcll(c2) == 1) return __builtin_amdgcn_readlane(tv.z, __ffsll((long long)c1) - 1);
   return -2;
 }
 
@@ -251,11 +272,6 @@ __device__ __forceinline__ void class_sums(int n, int lane, double& tg, double& 
   }
 }
 
-#ifdef EG_COOP_STAMPS      // diagnostic build (make ab AB=coopstamps ABFLAGS=-DEG_COOP_STAMPS; scripts/coop_stamps.py)
-#define EG_CS(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); cs[slot] += now_ - cs_last; cs_last = now_; } while (0)
-#else
-#define EG_CS(slot) do {} while (0)
-#endif
 
 // ---- phase 1, wave 0: the script (k_rollout's replay path without the placements; every value is the same in all 64 lanes).
 //      Leaves the lists in LDS and in the scratch record, the counts in `info`; returns false when the per-episode path must run. ----
@@ -299,16 +315,14 @@ __device__ __forceinline__ bool script(const DevTables& T, const DevSnapshot& S,
       class_sums(ngen, lane, tg, ig, sg);
     }
     bytes += 2ull * (unsigned long long)(n_existing + ngen) * 56ull + 2ull * (unsigned long long)noff * 8ull + 184ull;
-    int replay_idx = 0, replay_def_idx = 0, n_run_y = 0, n_def_y = 0, n_act_y = 0;
+    int replay_def_idx = 0, n_run_y = 0, n_def_y = 0, n_act_y = 0;
     const double balance0 = ((tg + ig) + sg) - usage;      // state_of(a).balance at the start of the year
-    int phase = balance0 < 0.0 ? 0 : 1;
-    double remaining = -balance0;
-    uint32_t attempts = 0, n_add = 0, k_add = 0;
-    bool n_add_known = false;
-    for (int guard = 0; guard < 200000; ++guard) {
-      int action;
-      if (phase == 0) {      // simulation.rs:319-522
-        if (!(remaining > 0.0)) { phase = 1; continue; }      // (the success bonus only touches the episode's private weights)
+    // ---- the repair loop (simulation.rs:319-522), one action at a time: every trip depends on the balance the last one left ----
+    if (balance0 < 0.0) {
+      double remaining = -balance0;
+      uint32_t attempts = 0;
+      for (int guard = 0; guard < 200000 && remaining > 0.0; ++guard) {      // (the success bonus behind it only touches the episode's private weights)
+        int action;
         attempts += 1;
         if (attempts < 5u) {      // sampling.rs:242-313
           if (replay_def_idx >= repd_n) return false;      // smart_deficit_fallback: a seeded draw
@@ -318,22 +332,9 @@ __device__ __forceinline__ bool script(const DevTables& T, const DevSnapshot& S,
           if (lane == 0) def_log[def_pos] = (uint8_t)action;
           def_pos += 1; n_def_y += 1;
         } else action = 3 * kBattery;      // simulation.rs:369-376
-        if (action >= kFirstOffset) continue;
-      } else {
-        if (!n_add_known) { n_add_known = true; n_add = (uint32_t)rep_n; }      // simulation.rs:146-162
-        if (k_add >= n_add) break;
-        k_add += 1;
-        // sampling.rs:78-145 (replay_idx < rep_n: the count IS the list's length)
-        action = replay_idx < kWave ? __builtin_amdgcn_readlane(rep0, replay_idx)
-                                    : (replay_idx < 2 * kWave ? __builtin_amdgcn_readlane(rep1, replay_idx - kWave) : (int)S.best_actions()[rep_lo + replay_idx]);
-        replay_idx += 1;
-        if (run_pos >= EG_RUN_CAP) return false;
-        if (lane == 0) run_log[run_pos] = (uint8_t)action;
-        run_pos += 1; n_run_y += 1;
-      }
-      action = __builtin_amdgcn_readfirstlane(action);
-      if (action < kFirstOffset) {      // actions.rs:42-91: the placement itself is phase 2's
-        const int t = action / 3, m = action - 3 * t;
+        action = __builtin_amdgcn_readfirstlane(action);
+        if (action >= kFirstOffset) continue;      // only AddGenerator actions are applied in the repair loop (:398)
+        const int t = action / 3, m = action - 3 * t;      // actions.rs:42-91: the placement itself is phase 2's
         bytes += (unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ngen) * 16ull;
         if (ngen >= gen_cap) return false;      // EG_EP_OVERFLOW
         if (lane == 0) { const uint16_t pk = (uint16_t)(t | (yi << 4) | (m << 9)); sc.gpack[ngen] = pk; gen_pack[ngen] = pk; }
@@ -341,23 +342,56 @@ __device__ __forceinline__ bool script(const DevTables& T, const DevSnapshot& S,
         const double out = sc.type_out[t];
         const int cls = (sc.tinfo[t] >> 9) & 3;
         if (cls == 1) ig += out; else if (cls == 2) sg += out; else tg += out;
-      } else if (action < kFirstOther) {      // actions.rs:121-181
-        const int ot = (action - kFirstOffset) / 3, m = (action - kFirstOffset) - 3 * ot;
-        if (noff >= off_cap) return false;
-        if (lane == 0) { const uint16_t p = (uint16_t)(ot | (yi << 4) | (m << 9)); sc.opack[noff] = p; off_pack[noff] = p; }
-        noff += 1;
-      }
-      if (phase == 0) {      // simulation.rs:406-486 (recorded twice, Q15; the nudges are dropped with the private tables)
+        // simulation.rs:406-486 (recorded twice, Q15; the nudges are dropped with the private tables)
         if (def_pos >= EG_DEF_CAP || n_def_y >= 128 || run_pos >= EG_RUN_CAP) return false;
         if (lane == 0) { def_log[def_pos] = (uint8_t)action; run_log[run_pos] = (uint8_t)action; }
         def_pos += 1; n_def_y += 1; run_pos += 1; n_run_y += 1;
         const double balance = ((tg + ig) + sg) - usage;
         remaining = -dmin(balance, 0.0);
-      } else {               // simulation.rs:193-197
-        if (act_pos >= EG_ACT_CAP || run_pos >= EG_RUN_CAP) return false;
-        if (lane == 0) { act_log[act_pos] = (uint8_t)action; run_log[run_pos] = (uint8_t)action; }
-        act_pos += 1; n_act_y += 1; run_pos += 1; n_run_y += 1;
       }
+    }
+    // ---- the year's additional actions (simulation.rs:144-198): the whole list (its length IS the count, :146-162; sampling.rs:78-145
+    //      hands out entry after entry), 64 actions at a time — a lane an action: logs, list entries and counts in parallel, the class
+    //      sums folded in list order ----
+    for (int done = 0; done < rep_n; done += kWave) {
+      const int i = done + lane, cnt = rep_n - done < kWave ? rep_n - done : kWave;
+      const bool valid = i < rep_n;
+      int a = done == 0 ? rep0 : rep1;
+      if (done >= 2 * kWave) a = valid ? (int)S.best_actions()[rep_lo + i] : 0;
+      const bool isg = valid && a < kFirstOffset, iso = valid && a >= kFirstOffset && a < kFirstOther;
+      const unsigned long long mg = __ballot(isg), mo = __ballot(iso), below = (1ull << lane) - 1ull;
+      const int ng = __popcll(mg), no = __popcll(mo);
+      // (what the action-by-action loop checks before every store, for the whole block: any of them ends the hoist)
+      if (ngen + ng > gen_cap || noff + no > off_cap || run_pos + 2 * cnt > EG_RUN_CAP || act_pos + cnt > EG_ACT_CAP) return false;
+      if (valid) {      // recorded by the sampler and again by the caller (Q15), and as an action of the result
+        run_log[run_pos + 2 * lane] = (uint8_t)a; run_log[run_pos + 2 * lane + 1] = (uint8_t)a;
+        act_log[act_pos + lane] = (uint8_t)a;
+      }
+      double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+      if (isg) {
+        const int t = a / 3, m = a - 3 * t, at = ngen + __popcll(mg & below);
+        const uint16_t pk = (uint16_t)(t | (yi << 4) | (m << 9));
+        sc.gpack[at] = pk; gen_pack[at] = pk;
+        const int cls = (sc.tinfo[t] >> 9) & 3;
+        const double out = sc.type_out[t];
+        x0 = (cls != 1 && cls != 2) ? out : 0.0; x1 = cls == 1 ? out : 0.0; x2 = cls == 2 ? out : 0.0;
+      }
+      if (iso) {
+        const int ot = (a - kFirstOffset) / 3, m = (a - kFirstOffset) - 3 * ot, at = noff + __popcll(mo & below);
+        const uint16_t pp = (uint16_t)(ot | (yi << 4) | (m << 9));
+        sc.opack[at] = pp; off_pack[at] = pp;
+      }
+      // Σ over the block's generators of kCells * 8 + (n_existing + generators before it) * 16
+      bytes += (unsigned long long)ng * ((unsigned long long)kCells * 8ull + (unsigned long long)(n_existing + ngen) * 16ull) +
+               8ull * (unsigned long long)ng * (unsigned long long)(ng > 0 ? ng - 1 : 0);
+      if (ng > 0)
+        for (int r = 0; r * 16 < cnt; ++r) {      // (+0.0 from every lane that is not a generator of that class: sums of non-negative terms)
+          double a0 = tg, a1 = ig;
+          fold2_row16(a0, x0, a1, x1);
+          const double a2 = fold_row16(sg, x2);
+          tg = readlane_f64(a0, 16 * r); ig = readlane_f64(a1, 16 * r); sg = readlane_f64(a2, 16 * r);
+        }
+      ngen += ng; noff += no; run_pos += 2 * cnt; n_run_y += 2 * cnt; act_pos += cnt; n_act_y += cnt;
     }
     bytes += 2ull * (unsigned long long)(n_act_y + n_def_y);
     if (lane == 0) {
@@ -429,9 +463,14 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
     for (int k = 0; k < kPer; ++k) base[v][k] = 0.0;
   int cur_year = -1, slow = 0, years = 0;
   bool failed = false;
+  // (the list entry and the type's word of a placement are read during the placement before it: two dependent LDS round trips less)
+  int pk_next = n_gens > 0 ? (int)sc.gpack[0] : 0;
+  int info_next = sc.tinfo[pk_next & 15];
   for (int g = 0; g < n_gens; ++g) {
-    const int pk = __builtin_amdgcn_readfirstlane((int)sc.gpack[g]);
+    const int pk = __builtin_amdgcn_readfirstlane(pk_next);
+    const int info_t = __builtin_amdgcn_readfirstlane(info_next);
     const int t = pk & 15, yi = (pk >> 4) & 31;
+    pk_next = (int)sc.gpack[g + 1 < n_gens ? g + 1 : g];
     if (yi != cur_year) {      // a new year: its scores (tab::cbase, per cell), one round trip
       cur_year = yi; years += 1;
 #pragma unroll
@@ -445,17 +484,16 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
         }
       EG_CS(2);      // 2: year changes (requests; the wait lands in the first search)
     }
-    const int info_t = __builtin_amdgcn_readfirstlane(sc.tinfo[t]);
     const int v = info_t & 15, rc = (info_t >> 4) & 15;
     int cell;
     switch (v) {      // (uniform: each case reads its own registers — no copies)
-#define EG_SCAN(V_) case V_: cell = scan_fast(base[V_], rc, tid, lane, wave); break;
+#define EG_SCAN(V_) case V_: cell = scan_fast(base[V_], rc, tid, lane, wave EG_CS_PASS); break;
       EG_SCAN(1) EG_SCAN(2) EG_SCAN(3) EG_SCAN(4) EG_SCAN(5) EG_SCAN(6) EG_SCAN(7)
       static_assert(kVariants == 8, "a case a variant");
 #undef EG_SCAN
-      default: cell = scan_fast(base[0], rc, tid, lane, wave); break;
+      default: cell = scan_fast(base[0], rc, tid, lane, wave EG_CS_PASS); break;
     }
-    EG_CS(3);      // 3: searches (fast path)
+    EG_CS(7);      // 7: searches: the decision
     if (cell == -2) {      // several cells within reach of the maximum, or nothing decided (rare)
       double tb[kPer];
 #pragma unroll
@@ -465,10 +503,10 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
         if (vv == v) { _Pragma("unroll") for (int k = 0; k < kPer; ++k) tb[k] = base[vv][k]; }
       cell = scan_slow(T, tb, yi, t, g, tid, lane, wave);
       slow += 1;
-      EG_CS(4);      // 4: searches (slow path)
     }
     if (cell < 0) { failed = true; break; }      // EG_EP_NO_LOCATION: the per-episode path reports it
     if (tid == 0) { sc.gcell[g] = (uint16_t)cell; gen_cell[g] = (uint16_t)cell; }
+    info_next = sc.tinfo[pk_next & 15];      // (pk_next has long arrived)
     field_add(E, cell);
     wg_barrier_lds();
     EG_CS(5);      // 5: field updates + their barrier
@@ -477,8 +515,9 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
     info->lens[5] = slow;
     *O.n_chunks(0) = (uint32_t)(years * ((nv * kCells * 8 + 2047) / 2048) + slow);      // the years' score tables, in units of 2 KB
 #ifdef EG_COOP_STAMPS
-    EG_CS(6);
     for (int i = 0; i < 8; ++i) info->stamps[i] = cs[i];
+#else
+    info->stamps[7] = (unsigned long long)slow;      // (eg_debug_hoist_stamps: searches that needed more than the one exchange)
 #endif
     __threadfence();
     __hip_atomic_store(&info->coop_seq, hoist_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

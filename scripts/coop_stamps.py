@@ -23,7 +23,7 @@ for _ in range(GROW):
     tr.step()
 tr.sync()
 eng.replay_hoist(True)
-names = ["set-up", "script (phase 1)", "year changes (requests)", "searches, fast path", "searches, slow path", "field updates + barrier", "tail", "-"]
+names = ["set-up", "script (phase 1)", "year changes (requests)", "search: the lane's cells", "search: the wave's two largest", "field updates + barrier", "search: exchange barrier", "search: decision (+ slow path)"]
 for label, n, mask in (("alone", 64, np.ones(64, np.uint8)), ("beside a lean grid", 16384, (np.arange(16384) % 10 == 0).astype(np.uint8))):
     for rep in range(2):
         res = eng.rollout_batch(w, 12345, n, replay_mask=mask)
@@ -32,5 +32,5 @@ for label, n, mask in (("alone", 64, np.ones(64, np.uint8)), ("beside a lean gri
     tot = sum(st)
     g = int(res.n_gens[0])
     print(f"{label}: {g} generators, served {eng.replay_hoist_stats()[1]}, {tot} cycles = {tot / 2.4e3:.1f} us at 2.4 GHz (100 MHz counter? see below)")
-    for k in range(7):
+    for k in range(8):
         print(f"   {names[k]:26s} {st[k]:10d}  {100.0 * st[k] / max(tot, 1):5.1f} %   per placement {st[k] / max(g, 1):8.1f}")
