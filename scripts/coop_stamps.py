@@ -14,14 +14,27 @@ from eirgrid_amd.engine import ActionWeights, Engine
 from eirgrid_amd.parallel import BatchTrainer
 
 GROW = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+SHARDS = int(sys.argv[2]) if len(sys.argv) > 2 else 1      # > 1: the policy grown at the global batch of that many shards (hoist_probe.py)
 eng = Engine(synthetic_world())
 w = ActionWeights()
 first = eng.run_iteration(0, w, False, 12345)
 w.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0], first.def_log[0, :first.n_def[0].sum()])
-tr = BatchTrainer(eng, w, 16384, 12345, replay_fraction=0.1)
-for _ in range(GROW):
-    tr.step()
-tr.sync()
+if SHARDS > 1:
+    eng.replay_hoist(True)      # (the same policies either way — tests/test_gpu_replay_hoist.py — and an eighth of the time)
+    eng.push(w)
+    packets = torch.zeros(SHARDS * N.PACKET_BYTES, dtype=torch.uint8, device="cuda")
+    for s in range(GROW):
+        for r in range(SHARDS):
+            eng.device_rollout(12345, (s * SHARDS + r) * 16384, 16384, 10, packets.data_ptr() + r * N.PACKET_BYTES)
+        eng.device_apply(packets.data_ptr(), SHARDS, packets.data_ptr(), 12345 + s)
+        for r in range(1, SHARDS):
+            packets[r * N.PACKET_BYTES:r * N.PACKET_BYTES + 8 * N.STATS_LEN] = 0
+    eng.pull(w)
+else:
+    tr = BatchTrainer(eng, w, 16384, 12345, replay_fraction=0.1)
+    for _ in range(GROW):
+        tr.step()
+    tr.sync()
 eng.replay_hoist(True)
 names = ["set-up", "script (phase 1)", "year changes (requests)", "search: the lane's cells", "search: the wave's two largest", "field updates + barrier", "search: exchange barrier", "search: decision (+ slow path)"]
 for label, n, mask in (("alone", 64, np.ones(64, np.uint8)), ("beside a lean grid", 16384, (np.arange(16384) % 10 == 0).astype(np.uint8))):
