@@ -59,7 +59,7 @@ class EgEpisodeOut(C.Structure):
 EXPORTS = [
     "eg_build_hash", "eg_last_error", "eg_device_count", "eg_create", "eg_destroy", "eg_rollout_batch", "eg_upload_snapshot",
     "eg_rollout_launch", "eg_rollout_launch_update", "eg_sync", "eg_last_batch_size", "eg_policy_hold", "eg_policy_rewind", "eg_replay_hoist", "eg_replay_hoist_stats", "eg_debug_hoist_stamps", "eg_fetch", "eg_timing_reset", "eg_timing_read", "eg_timing_read_grids", "eg_memory_report", "eg_update_stats", "eg_fetch_scores",
-    "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_best_result_track", "eg_fetch_best_result", "eg_evaluate_action_impact", "eg_place", "eg_find_suitable_location", "eg_debug_fill_lds", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
+    "eg_fetch_episode_lists", "eg_fetch_record", "eg_fetch_best_run", "eg_best_result_track", "eg_fetch_best_result", "eg_evaluate_action_impact", "eg_place", "eg_find_suitable_location", "eg_debug_fill_lds", "eg_debug_occupy", "eg_policy_apply_reduced", "eg_policy_apply_packet", "eg_train_step",
     "eg_policy_push", "eg_device_rollout", "eg_device_apply", "eg_device_step", "eg_policy_pull",
     "eg_host_tables_create", "eg_host_tables_free", "eg_host_tables_f64", "eg_host_tables_i32",
     "eg_policy_new", "eg_policy_free", "eg_policy_snapshot_view", "eg_policy_get_tables", "eg_policy_set_tables",
@@ -181,6 +181,9 @@ def lib():
     L.eg_place.restype = C.c_int32
     L.eg_debug_fill_lds.restype = C.c_int32
     L.eg_debug_fill_lds.argtypes = [C.c_void_p, C.c_uint32]
+    if hasattr(L, "eg_debug_occupy") or not os.environ.get("EIRGRID_LIB"):
+        L.eg_debug_occupy.restype = C.c_int32
+        L.eg_debug_occupy.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
     L.eg_place.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _u16p, C.c_int32, _i32p, _dp]
     L.eg_host_tables_create.restype = C.c_void_p
     L.eg_host_tables_create.argtypes = [C.POINTER(EgWorld)]

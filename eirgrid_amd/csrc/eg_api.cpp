@@ -110,6 +110,7 @@ struct eg_ctx {
   unsigned long long hoist_seq = 0;
   HoistInfo* d_hoist = nullptr; uint8_t* d_coop = nullptr;
   uint64_t hoist_batches = 0;      // batches launched with the hoist armed (eg_replay_hoist_stats)
+  long long* d_stats_rep = nullptr;      // kStatsReplicas copies of the statistics array (RolloutPlan::d_stats_rep); EIRGRID_STATS_REPLICAS=0: none
 };
 
 namespace {
@@ -247,6 +248,15 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   plan.skip_long = c->list_exact && !list_long;
   int rc = prepare_heavy(c, plan.n_heavy, plan.skip_long);
   if (rc != EG_OK) return rc;
+  if (d_stats != nullptr) {      // the statistics epilogue adds to replicated arrays, folded into the packet behind the grids
+    static const bool off = [] { const char* e = std::getenv("EIRGRID_STATS_REPLICAS"); return e && e[0] == '0'; }();
+    if (!off && !c->d_stats_rep) {
+      const size_t bytes = sizeof(long long) * size_t(kStatsReplicas) * EG_STATS_LEN;
+      EG_HIP(hipMalloc((void**)&c->d_stats_rep, bytes));
+      EG_HIP(hipMemsetAsync(c->d_stats_rep, 0, bytes, nullptr));
+    }
+    plan.d_stats_rep = off ? nullptr : c->d_stats_rep;
+  }
   if (c->hoist_on && plan.n_heavy > 0) {      // the replay episodes of this batch are computed once (eg_replay_coop.h)
     plan.hoist_seq = ++c->hoist_seq; plan.d_hoist = c->d_hoist; plan.coop_out = c->d_coop;
     c->hoist_batches += 1;
@@ -267,6 +277,10 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
   if (split) {
     EG_HIP(hipEventRecord(c->ev_join[slot], c->stream_heavy));
     EG_HIP(hipStreamWaitEvent(nullptr, c->ev_join[slot], 0));
+  }
+  if (d_stats != nullptr && plan.d_stats_rep != nullptr) {
+    const int fs = launch_fold_stats(plan.d_stats_rep, d_stats, nullptr);
+    if (fs != 0) { set_error(std::string("k_fold_stats launch: ") + hipGetErrorString((hipError_t)fs)); return EG_ERR_HIP; }
   }
   if (c->fold_mode != 0) {      // behind the batch on the null stream: its results are in iteration order in the records
     const int fr = launch_fold_best(c->out, n, first_index, c->fold_mode == 2, c->d_fold, nullptr);
@@ -497,6 +511,7 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_snap_held) (void)hipFree(c->d_snap_held);
   if (c->d_fold) (void)hipFree(c->d_fold);
   if (c->d_hoist) (void)hipFree(c->d_hoist);
+  if (c->d_stats_rep) (void)hipFree(c->d_stats_rep);
   if (c->d_coop) (void)hipFree(c->d_coop);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->h_list_len) (void)hipHostFree(c->h_list_len);
@@ -639,6 +654,16 @@ int32_t eg_debug_fill_lds(eg_ctx* c, uint32_t value) {
   int lr = launch_fill_lds(value, reinterpret_cast<uint32_t*>(c->out.base), prop.multiProcessorCount * 8, nullptr);
   if (lr != 0) { set_error(std::string("k_fill_lds launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   EG_HIP(hipDeviceSynchronize());
+  return EG_OK;
+}
+
+int32_t eg_debug_occupy(eg_ctx* c, int32_t variant, uint64_t cycles) {
+  if (!c) return EG_ERR_BAD_ARG;
+  EG_HIP(hipSetDevice(c->device));
+  int rc = ensure_outputs(c, 1);
+  if (rc != EG_OK) return rc;
+  int lr = launch_occupy(variant, cycles, reinterpret_cast<uint32_t*>(c->out.score_list), c->stream_heavy);      // the library's side stream
+  if (lr != 0) { set_error(std::string("k_occupy launch: ") + hipGetErrorString((hipError_t)lr)); return EG_ERR_HIP; }
   return EG_OK;
 }
 

@@ -299,7 +299,13 @@ struct RolloutPlan {
   unsigned long long hoist_seq;
   HoistInfo* d_hoist;
   uint8_t* coop_out;
+  // statistics epilogue: kStatsReplicas copies of the statistics array — an episode adds to copy (workgroup index % kStatsReplicas) and
+  // k_fold_stats folds the copies into the packet behind the batch.  16 384 episodes adding to the same few hundred addresses are
+  // serialised address by address in L2: with the replay episodes hoisted that was 0.8 ms of a 1.9 ms batch (profiles/r04_ab_notes.log).
+  long long* d_stats_rep;
 };
+constexpr int kStatsReplicas = 64;
+int launch_fold_stats(long long* d_rep, long long* d_stats, void* stream);
 // d_hoist (device): what the kernels of the replay hoist hand each other
 struct HoistInfo {
   unsigned long long served_seq;      // written by k_replay_books: the batch whose replay episodes are served by the scratch record
@@ -316,6 +322,7 @@ constexpr size_t kHoistBytes = (sizeof(HoistInfo) + 63) & ~size_t(63);
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
                    uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& plan);
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream);      // test hook
+int launch_occupy(int variant, unsigned long long cycles, uint32_t* d_sink, void* stream);      // diagnostic hook (eg_debug_occupy)
 int launch_stalled_tables(uint8_t* d_snap, void* stream);
 // d_snap = d_held, except the count of failed episodes, which goes on counting (eg_policy_rewind)
 // (`list_len_out`: pinned host word, may be null — the length of the best list as the device now holds it, for the host's launch planning)

@@ -160,7 +160,7 @@ __device__ __forceinline__ int scan_fast(const double (&b)[kPer], int rc, int ti
 
 // ---- a search, slow path (several cells within reach of the maximum, or nothing decided): place_heavy's steps 2 and 3, then the
 //      exact scan.  `tb`: the lane's unpenalised scores.  Returns the cell, or -1: no candidate has a positive score. ----
-__device__ __noinline__ int scan_slow(const DevTables& T, const double (&tb)[kPer], int yi, int t, int ngen, int tid, int lane, int wave) {
+__device__ __forceinline__ int scan_slow(const DevTables& T, const double (&tb)[kPer], int yi, int t, int ngen, int tid, int lane, int wave) {
   const int info = __builtin_amdgcn_readfirstlane(sc.tinfo[t]);
   const int rc = (info >> 4) & 15, off = (int)((unsigned)info >> 24) << 1, cap = (info >> 16) & 255;
   const bool marine = ((info >> 8) & 1) != 0;

@@ -1648,6 +1648,7 @@ struct EpisodeMap {
   // episodes once and k_replay_broadcast hands every one of them the record: the replay variants have nothing to do (0: no hoist)
   const unsigned long long* hoist;
   unsigned long long hoist_seq;
+  uint32_t stats_rep;         // 1: `stats` is kStatsReplicas copies of the statistics array; this workgroup adds to copy (index % kStatsReplicas)
 };
 __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b) {
   if (m.mode == 0u) return b;
@@ -2233,7 +2234,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     wave_sync();
     StatsParams P;      // only needed here: not held in registers through the episode
     load_stats_params(S, P);
-    episode_update_stats(O, S, P, e, lane, stats);
+    episode_update_stats(O, S, P, e, lane, stats + (emap.stats_rep ? (size_t)(blockIdx.x % (uint32_t)kStatsReplicas) * EG_STATS_LEN : 0));
   }
 }
 
@@ -2761,14 +2762,14 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
                               const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
-                              void* stream, void* ev0, void* ev1);
+                              uint32_t stats_rep, void* stream, void* ev0, void* ev1);
 #ifdef EG_TU_THROUGHPUT
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
                               const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
-                              void* stream, void* ev0, void* ev1) {
+                              uint32_t stats_rep, void* stream, void* ev0, void* ev1) {
   EpisodeMap map{};
-  map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period; map.hoist = hoist; map.hoist_seq = hoist_seq;
+  map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period; map.hoist = hoist; map.hoist_seq = hoist_seq; map.stats_rep = stats_rep;
   // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
 #define EG_LAUNCH_TP(kKind) hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, \
                                                   t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map)
@@ -2789,16 +2790,20 @@ void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s,
                           d_replay_mask, replay_period, d_stats, map);
   else
     (void)launch_rollout_throughput(kKind, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, map.count, map.mode, map.index, map.off, map.period,
-                                    map.hoist, map.hoist_seq, stream, ev0, ev1);
+                                    map.hoist, map.hoist_seq, map.stats_rep, stream, ev0, ev1);
 }
 }  // namespace
 
 int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index,
-                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, const RolloutPlan& p) {
+                   uint32_t n, const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats_packet, const RolloutPlan& p) {
   if (n == 0) return 0;
+  // the statistics go to the replicated array when the plan brings one (k_fold_stats, launched by the caller behind the grids, folds it
+  // into the packet)
+  const bool rep = d_stats_packet != nullptr && p.d_stats_rep != nullptr;
+  long long* d_stats = rep ? p.d_stats_rep : d_stats_packet;
   if (p.n_heavy > 0) {      // first, so that the long episodes start first: both replay variants, one of which returns at once
     EpisodeMap m{};
-    m.count = p.n_heavy;
+    m.count = p.n_heavy; m.stats_rep = rep ? 1u : 0u;
     if (p.n_lean == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index; }
     else { m.mode = 2u; m.off = p.off; m.period = p.period; }
@@ -2837,12 +2842,29 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
   }
   if (p.n_lean > 0) {
     EpisodeMap m{};
-    m.count = p.n_lean;
+    m.count = p.n_lean; m.stats_rep = rep ? 1u : 0u;
     if (p.n_heavy == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index + p.n_heavy; }
     else { m.mode = 3u; m.off = p.off; m.period = p.period; }
     launch_variant<kLean>(p.helper_waves, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, m, p.stream_lean, p.ev[2], p.ev[3]);
   }
+  return (int)hipGetLastError();
+}
+// The replicated statistics of a batch into its packet (sums; slot 3 is a maximum), and the copies cleared for the next batch.
+__global__ void __launch_bounds__(256) k_fold_stats(long long* rep, long long* stats) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= EG_STATS_LEN) return;
+  unsigned long long acc = 0ull;
+  for (int r = 0; r < kStatsReplicas; ++r) {
+    const unsigned long long v = (unsigned long long)rep[(size_t)r * EG_STATS_LEN + i];
+    acc = i == 3 ? (v > acc ? v : acc) : acc + v;
+    rep[(size_t)r * EG_STATS_LEN + i] = 0;
+  }
+  const unsigned long long old = (unsigned long long)stats[i];
+  stats[i] = (long long)(i == 3 ? (acc > old ? acc : old) : old + acc);
+}
+int launch_fold_stats(long long* d_rep, long long* d_stats, void* stream) {
+  hipLaunchKernelGGL(k_fold_stats, dim3((EG_STATS_LEN + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rep, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
@@ -2864,6 +2886,36 @@ __global__ void __launch_bounds__(256) k_fill_lds(uint32_t value, uint32_t* sink
   for (int i = threadIdx.x; i < 16384; i += 256) words[i] = value;
   __syncthreads();
   if (words[(threadIdx.x * 61u + blockIdx.x) & 16383u] != value) *sink = 1u;      // keeps the stores alive
+}
+// Diagnostic (eg_debug_occupy; scripts/side_kernel_probe.py): ONE workgroup that holds `kBytes` of LDS and its registers for `cycles` shader
+// cycles and does nothing — what does a resident workgroup of that footprint cost the grid that runs beside it?
+template <int kBytes, int kRegs, int kBusy = 0>
+__global__ void __launch_bounds__(256, 1) k_occupy(unsigned long long cycles, uint32_t* sink) {
+  __shared__ uint32_t words[kBytes / 4];
+  double r[kRegs];
+#pragma unroll
+  for (int i = 0; i < kRegs; ++i) r[i] = (double)(threadIdx.x + i);
+  words[threadIdx.x] = threadIdx.x;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < cycles) {
+#pragma unroll
+    for (int i = 0; i < kRegs; ++i) r[i] = r[i] * 1.0000001 + (double)words[(threadIdx.x + i) & 255];
+    if (kBusy == 0) __builtin_amdgcn_s_sleep(8);
+    if (kBusy >= 2) { words[(threadIdx.x * 7 + 1) & 255] = (uint32_t)r[0]; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < kRegs; ++i) acc += r[i];
+  if (acc == 12345.678) *sink = 1u;      // keeps the registers alive
+}
+int launch_occupy(int variant, unsigned long long cycles, uint32_t* d_sink, void* stream) {
+  if (variant == 0) hipLaunchKernelGGL((k_occupy<1024, 4>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);            // small in every way
+  else if (variant == 1) hipLaunchKernelGGL((k_occupy<150 * 1024, 4>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);  // the whole LDS of a CU
+  else if (variant == 2) hipLaunchKernelGGL((k_occupy<1024, 100>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);       // 200+ registers a lane
+  else if (variant == 3) hipLaunchKernelGGL((k_occupy<150 * 1024, 100>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);  // both
+  else if (variant == 4) hipLaunchKernelGGL((k_occupy<150 * 1024, 100, 1>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);  // both, busy (no sleep)
+  else hipLaunchKernelGGL((k_occupy<150 * 1024, 100, 2>), dim3(1), dim3(256), 0, (hipStream_t)stream, cycles, d_sink);                   // both, busy, LDS writes and barriers
+  return (int)hipGetLastError();
 }
 int launch_fill_lds(uint32_t value, uint32_t* d_sink, int n_workgroups, void* stream) {
   hipLaunchKernelGGL(k_fill_lds, dim3(n_workgroups), dim3(256), 0, (hipStream_t)stream, value, d_sink);

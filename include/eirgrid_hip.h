@@ -249,6 +249,10 @@ double eg_evaluate_action_impact(const double current_metrics[4], const double n
  * kernel that reads a word before writing it sees what the previous tenant left; the parity tests call this with small
  * integers (the values the helper protocol's sequence flags take) before a rollout. */
 int32_t eg_debug_fill_lds(eg_ctx *, uint32_t value);
+/* Diagnostic hook: ONE idle workgroup of 256 threads on the library's side stream that stays resident for `cycles` shader cycles;
+ * variant 0: 1 KB of LDS, few registers; 1: 150 KB of LDS; 2: 200+ registers a lane; 3: both (the hoisted replay's footprint).  What a
+ * resident workgroup costs the grid beside it: scripts/side_kernel_probe.py, profiles/r04_ab_notes.log. */
+int32_t eg_debug_occupy(eg_ctx *, int32_t variant, uint64_t cycles);
 
 /* B2: one placement search on the device (settlements of year index `year_index`, the ctx's existing plant plus
  * `n_extra` generators given by grid cell), for parity tests of the arg-max kernel. */

@@ -20,11 +20,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 GROW = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 BATCHES = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 SHARDS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+FRESH = len(sys.argv) > 5 and sys.argv[5] == "fresh"      # no seeded best strategy: the loop from ActionWeights::new
 torch.cuda.set_device(0)
 eng = Engine(synthetic_world())
 w = ActionWeights()
-first = eng.run_iteration(0, w, False, 12345)
-w.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0], first.def_log[0, :first.n_def[0].sum()])
+if not FRESH:
+    first = eng.run_iteration(0, w, False, 12345)
+    w.apply_episode(first.metrics[0], first.n_run[0], first.run_log[0, :first.n_run[0].sum()], first.n_def[0], first.def_log[0, :first.n_def[0].sum()])
 
 
 def grow_global(w, shards, steps):
@@ -73,6 +75,26 @@ def timed(hoist):
             "served": eng.replay_hoist_stats()[1] if hoist else None}
 
 
+def timed_no_update(hoist):
+    """the same batches without the statistics epilogue and the update (eg_rollout_launch): rollout grids only"""
+    eng.replay_hoist(hoist)
+    eng.upload_snapshot(w)
+    mask = (np.arange(B) % 10 == 0).astype(np.uint8)
+    for _ in range(5):
+        eng.launch(12345, 0, B, mask)
+    eng.sync(); eng.timing_reset()
+    for _ in range(50):
+        eng.launch(12345, 0, B, mask)
+    eng.sync()
+    span, grids, n = eng.timing_read_grids()
+    return {"hoist": hoist, "no_update": True, "rollout_span_ms": span / n, "sum_of_grids_ms": grids / n}
+
+
+tr.sync()
+for hoist in (False, True):
+    print(json.dumps(timed_no_update(hoist)), flush=True)
+tr = BatchTrainer(eng, w, B, 12345, replay_fraction=0.1)
+tr.pin_policy()
 for rep in range(3):
     for hoist in (False, True):
         r = timed(hoist)

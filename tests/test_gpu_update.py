@@ -222,11 +222,13 @@ def test_bench_line_contract_on_one_gpu():
     # ... the same batches with the replay hoist on (the replay episodes computed once): same episodes, served by the hoist
     h = line["config2_replay_hoisted"]
     assert h["replay_hoist"] and h["hoist_served_last_batch"] and h["value"] > 0 and h["episodes_failed"] == 0
-    assert h["last_batch"] == cfg["last_batch"] and h["replay"] == cfg["replay"] and h["speedup_vs_value"] > 0
+    same = ("ok", "overflow", "other_failures", "replay_episodes", "generators_per_replay_episode")      # (the sampled episodes of the last batch are others)
+    assert all(h["last_batch"][k] == cfg["last_batch"][k] for k in same) and h["replay"] == cfg["replay"] and h["speedup_vs_value"] > 0
     # ... one rank's batch in the state of the 8-GPU loop, and the loop from a fresh policy: per-episode replays and hoisted
     for key in ("config3_one_rank_state", "fresh_policy_steady_state"):
         a, b = line[key]["per_episode_replays"], line[key]["replay_hoisted"]
-        assert a["value"] > 0 and b["value"] > 0 and a["episodes_failed"] == 0 and b["episodes_failed"] == 0 and a["last_batch"] == b["last_batch"]
+        assert a["value"] > 0 and b["value"] > 0 and a["episodes_failed"] == 0 and b["episodes_failed"] == 0
+        assert all(a["last_batch"][k] == b["last_batch"][k] for k in same)
         assert not a["replay_hoist"] and b["replay_hoist"]
     # the primary ceiling is first in the roofline object, the byte accounting labelled as such
     assert list(r)[:4] == ["bound", "valu_busy", "valu_busy_grids", "issue_slot_frac"] and "accounting" in r and "north_star_40pct_of_hbm" in r
