@@ -222,7 +222,8 @@ def test_bench_line_contract_on_one_gpu():
     # ... the same batches with the replay hoist on (the replay episodes computed once): same episodes, served by the hoist
     h = line["config2_replay_hoisted"]
     assert h["replay_hoist"] and h["hoist_served_last_batch"] and h["value"] > 0 and h["episodes_failed"] == 0
-    same = ("ok", "overflow", "other_failures", "replay_episodes", "generators_per_replay_episode")      # (the sampled episodes of the last batch are others)
+    # (the sampled episodes of the last batch are others, and a window of 2 048 indices holds 204 or 205 multiples of ten)
+    same = ("ok", "overflow", "other_failures", "generators_per_replay_episode")
     assert all(h["last_batch"][k] == cfg["last_batch"][k] for k in same) and h["replay"] == cfg["replay"] and h["speedup_vs_value"] > 0
     # ... one rank's batch in the state of the 8-GPU loop, and the loop from a fresh policy: per-episode replays and hoisted
     for key in ("config3_one_rank_state", "fresh_policy_steady_state"):
