@@ -139,7 +139,7 @@ def sq_counters(workload: str):
     out = {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / eps,
            "salu_insts_per_episode": run.get("SQ_INSTS_SALU", 0.0) / eps, "lds_insts_per_episode": run.get("SQ_INSTS_LDS", 0.0) / eps,
            "issue_slot_frac": insts / slots if slots > 0 else None}
-    for v in ("heavy", "short", "lean"):      # a batch with replay episodes: the grids of the launch, measured one after the other
+    for v in ("heavy", "short", "lean", "coop"):      # a batch with replay episodes: the grids of the launch, measured one after the other
         if isinstance(run.get(v), dict) and "valu_busy" in run[v]:
             out[f"valu_busy_{v}_grid"] = run[v]["valu_busy"]
     return out
@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--trajectory", action="store_true",
                     help="let the policy evolve from batch to batch (the training loop as it runs) instead of starting every batch "
                          "from the seeded policy; what a replay episode costs then depends on the run and on N (SURVEY Q15)")
+    ap.add_argument("--replay-hoist", action="store_true",
+                    help="measure the HEADLINE with the replay hoist on (eg_replay_hoist: the batch's replay episodes computed once) — for profiling "
+                         "that path; the default line executes every episode on its own and reports the hoisted batches as `config2_replay_hoisted`")
     ap.add_argument("--no-yearly", action="store_true", help="skip the 26x21 yearly rows (the reference always produces them)")
     args = ap.parse_args()
     # The headline is the SUSTAINED state of configs[2]: the policy the single-GPU training loop holds GROW_BATCHES batches after the
@@ -413,6 +416,7 @@ def main():
                            force_collectives=args.force_collectives, device_resident=True)
     if not args.trajectory:
         trainer.pin_policy()
+    eng.replay_hoist(bool(args.replay_hoist))
 
     def fence():
         if use_dist:
@@ -475,8 +479,9 @@ def main():
     if use_dist:
         digests = [None] * world_size
         dist.all_gather_object(digests, policy_digest(weights))
+    eng.replay_hoist(False)
     wkey = workload_key(args.episodes, args.replay_fraction) + ("grown" if args.grown and args.replay_fraction > 0.0 else "") \
-        + ("traj" if args.trajectory else "")
+        + ("hoist" if args.replay_hoist else "") + ("traj" if args.trajectory else "")
 
     line = None
     if rank == 0:
@@ -495,7 +500,7 @@ def main():
                                       "semantics incl. its double recording, SURVEY Q15)" if trainer.replay_period else ", no replay")
                                    + "; batch pass = rollout (grid step + tabular policy sampling) + batch policy update on the device; synthetic world "
                                      "S=130 settlements / G0=59 existing plant / P=200 coast points, seed 12345",
-                       "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction,
+                       "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction, "replay_hoist": bool(args.replay_hoist),
                        "batches_timed": m["batches"], "episodes_failed": m["failed"],
                        "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one all-gather of {N_PACKET_BYTES} bytes per rank per update "
                                       "(integer statistics summed in the update kernel)",
@@ -514,7 +519,7 @@ def main():
     # ---- the same batches with the replay hoist on (include/eirgrid_hip.h eg_replay_hoist): the replay episodes of a batch — one and
     #      the same computation — computed once, every record / packet / policy byte-identical (tests/test_gpu_replay_hoist.py).
     #      `value` above executes every episode on its own, as before; this object is the same workload with that redundancy removed. ----
-    def side_object(w, hoist: bool, what: str):
+    def side_object(w, hoist: bool, what: str, profile_key: str = None):
         """One more pinned measurement of `w` on this engine (all ranks take part: the same collectives as the headline)."""
         tr = BatchTrainer(eng, w, args.episodes, args.seed, rank, world_size, dist if use_dist else None, replay_fraction=args.replay_fraction,
                           write_yearly=not args.no_yearly, force_collectives=args.force_collectives, device_resident=True)
@@ -523,18 +528,22 @@ def main():
         g = measure(tr, w)
         served = eng.replay_hoist_stats()[1] if hoist else None
         eng.replay_hoist(False)
-        return {"workload": what, "replay_hoist": hoist, "hoist_served_last_batch": served,
-                "value": g["value"], "unit": "episodes/s", "batches_timed": g["batches"], "timed_region_s": g["elapsed"],
-                "ms_per_batch": g["elapsed"] / g["batches"] * 1e3, "episodes_failed": g["failed"],
-                "rollout_span_ms": g["avg_kernel_s"] * 1e3, "sum_of_grids_ms": g["avg_grids_s"] * 1e3,
-                "last_batch": {k: g["census"][k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
-                                                           "generators_per_seeded_episode", "generators_per_replay_episode")},
-                "replay": g["replay"]}
+        obj = {"workload": what, "replay_hoist": hoist, "hoist_served_last_batch": served,
+               "value": g["value"], "unit": "episodes/s", "batches_timed": g["batches"], "timed_region_s": g["elapsed"],
+               "ms_per_batch": g["elapsed"] / g["batches"] * 1e3, "episodes_failed": g["failed"],
+               "rollout_span_ms": g["avg_kernel_s"] * 1e3, "sum_of_grids_ms": g["avg_grids_s"] * 1e3,
+               "last_batch": {k: g["census"][k] for k in ("ok", "overflow", "other_failures", "replay_episodes",
+                                                          "generators_per_seeded_episode", "generators_per_replay_episode")},
+               "replay": g["replay"]}
+        if profile_key and rank == 0:
+            obj["roofline"] = roofline_object(profile_key, g["census"], args.episodes, g["avg_kernel_s"])
+        return obj
 
     extras = args.replay_fraction > 0.0 and not args.trajectory and not args.no_config1
     hoisted = side_object(seeded_policy(args.grown), True,
                           "the headline's batches (same pinned policy, same episodes, same update) with the replay hoist on: the batch's replay "
-                          "episodes are computed once by a cooperative workgroup and handed to every replay slot") if extras else None
+                          "episodes are computed once by a cooperative workgroup and handed to every replay slot",
+                          workload_key(args.episodes, args.replay_fraction) + ("grown" if args.grown else "") + "hoist") if extras else None
     sustained_n = None
     if extras and world_size > 1:
         # What the N-GPU loop itself sustains: the reference's replayed list grows with the GLOBAL batch (Q15), so the state an N-rank run

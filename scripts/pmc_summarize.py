@@ -4,6 +4,7 @@
 
 Each dir is the -d directory of one counter pass of `python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --batches-per-step 2 ...` of that
 workload ("16384r0.1" = BASELINE configs[2], the default; "16384r0.1grown" = the same from the grown-replay state, --grown;
+"16384r0.1grownhoist" = the grown state with the replay hoist on, --replay-hoist: k_replay_coop / _books / _broadcast are counted too;
 "1024" = configs[1]).  A batch with replay episodes is two
 k_rollout grids for the replays (`k_rollout<.., 2>`, the heavy-capable variant, and `k_rollout<.., 1>`, the short-replay one:
 whichever the length of the best list does not call for returns at once) and the lean one (`k_rollout<.., 0>`) for the rest; the
@@ -18,13 +19,18 @@ import csv, glob, json, os, sys
 TIMED = 8
 
 
+VARIANTS = ("heavy", "short", "lean", "coop", "books", "bcast")
+
+
 def variant_of(name):      # k_rollout<helpers, kind>: kind 2 = long-replay (heavy-capable) variant, 1 = short-replay, 0 = lean
+    for key, v in (("k_replay_coop", "coop"), ("k_replay_books", "books"), ("k_replay_broadcast", "bcast")):      # the replay hoist's kernels
+        if key in name: return v
     if "k_rollout" not in name: return None
     return "heavy" if ", 2>" in name else ("short" if ", 1>" in name else "lean")
 
 
 def rows(d, counter):
-    out = {"heavy": [], "short": [], "lean": []}
+    out = {v: [] for v in VARIANTS}
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             v = variant_of(r["Kernel_Name"])
@@ -52,13 +58,14 @@ def main():
     for spec in specs:
         wl, fd, wd = spec.split(":")
         f, w = rows(fd, "FETCH_SIZE"), rows(wd, "WRITE_SIZE")
-        if not f["lean"] and not f["heavy"] and not f["short"]:
+        if not any(f[v] for v in ("lean", "heavy", "short")):
             raise SystemExit(f"no k_rollout rows under {fd}")
         fa = sum(avg(f[v], "value_kb") for v in f); wa = sum(avg(w[v], "value_kb") for v in w)
         doc["configs"][wl] = dict(workload=wl, launches=max(len(f[v]) for v in f), fetch_size_kb_avg=fa, write_size_kb_avg=wa,
                                   hbm_bytes_per_launch=2 * fa * 1024 + wa * 1024,
-                                  kernel_ns=sum(avg(f[v], "dur_ns") for v in f),
+                                  kernel_ns=sum(avg(f[v], "dur_ns") for v in ("heavy", "short", "lean")),
                                   kernel_ns_heavy=avg(f["heavy"], "dur_ns"), kernel_ns_short=avg(f["short"], "dur_ns"), kernel_ns_lean=avg(f["lean"], "dur_ns"),
+                                  kernel_ns_hoist=sum(avg(f[v], "dur_ns") for v in ("coop", "books", "bcast")),
                                   fetch_rows=f, write_rows=w)
     path = os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.json")
     json.dump(doc, open(path, "w"), indent=1)
