@@ -299,7 +299,7 @@ struct RolloutPlan {
   unsigned long long hoist_seq;
   HoistInfo* d_hoist;
   uint8_t* coop_out;
-  // statistics epilogue: kStatsReplicas copies of the statistics array — an episode adds to copy (workgroup index % kStatsReplicas) and
+  // statistics epilogue: kStatsReplicas copies of the statistics array, entry-major — an episode adds to copy (workgroup index % kStatsReplicas) and
   // k_fold_stats folds the copies into the packet behind the batch.  16 384 episodes adding to the same few hundred addresses are
   // serialised address by address in L2: with the replay episodes hoisted that was 0.8 ms of a 1.9 ms batch (profiles/r04_ab_notes.log).
   long long* d_stats_rep;

@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
 // episode_update_stats times that — 1 638 waves adding to the same few hundred addresses one after the other took 0.3 ms) and
 // publishes HoistInfo::served_seq.
 __global__ void __launch_bounds__(kWave) k_replay_books(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long hoist_seq, HoistInfo* info,
-                                                        long long* stats, uint32_t n_replay) {
+                                                        long long* stats, uint32_t n_replay, int stats_rep) {
   if (__hip_atomic_load(&info->coop_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != hoist_seq) return;      // the script was not hoisted
   const int lane = threadIdx.x;
   const int yi = blockIdx.x;
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(kWave) k_replay_books(DevTables T, DevSnapshot
     wave_sync();
     DevSnapshot S = S_in; StatsParams P;
     load_state(S); load_stats_params(S, P);
-    episode_update_stats(O, S, P, 0u, lane, stats, (unsigned long long)n_replay);
+    episode_update_stats(O, S, P, 0u, lane, stats, (unsigned long long)n_replay, stats_rep ? 0 : -1);
   }
   __threadfence();
   if (lane == 0) __hip_atomic_store(&info->served_seq, hoist_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -1544,23 +1544,27 @@ __device__ __forceinline__ void load_state(DevSnapshot& S) {
 // One wave adds the contributions of episode e (its outputs must be visible in memory).
 // `mult`: the episode stands for that many identical ones (the hoisted replay, eg_replay_coop.h): every sum receives mult times its
 // contribution — integers, so that IS adding it mult times.
+// `rep` >= 0: `stats` is the replicated form — kStatsReplicas copies, ENTRY-major (copy r of entry i at i * kStatsReplicas + r, so that
+// k_fold_stats reads the copies of an entry as one 512-byte line) — and this episode adds to copy `rep`.
 __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, const StatsParams& P, uint32_t e, int lane, long long* stats,
-                                     unsigned long long mult = 1ull) {
-  unsigned long long* st = reinterpret_cast<unsigned long long*>(stats);
+                                     unsigned long long mult = 1ull, int rep = -1) {
+  unsigned long long* const st0 = reinterpret_cast<unsigned long long*>(stats);
+  const int stride = rep >= 0 ? kStatsReplicas : 1, ro = rep >= 0 ? rep : 0;
+#define st(i_) st0[(size_t)(i_) * stride + ro]
   if (*O.status(e) != EG_EP_OK) {
-    if (lane == 0) { atomicAdd(&st[1], mult); *O.score(e) = -1.0; O.score_list[e] = -1.0; }
+    if (lane == 0) { atomicAdd(&st(1), mult); *O.score(e) = -1.0; O.score_list[e] = -1.0; }
     return;
   }
   const double score = rm::score(O.metrics(e));
-  // st[3]: the batch's best score as an integer that sorts like the score (scores are not negative; + 1 so that 0 means
+  // slot 3: the batch's best score as an integer that sorts like the score (scores are not negative; + 1 so that 0 means
   // "no successful episode"): with one GPU k_apply_update finds the best episode from it without a kernel of its own
-  if (lane == 0) { atomicAdd(&st[0], mult); *O.score(e) = score; O.score_list[e] = score; atomicMax(&st[3], (unsigned long long)__double_as_longlong(score) + 1ull); }
+  if (lane == 0) { atomicAdd(&st(0), mult); *O.score(e) = score; O.score_list[e] = score; atomicMax(&st(3), (unsigned long long)__double_as_longlong(score) + 1ull); }
   if (!P.has_best) return;
   const double det = P.best_score > 0.0 ? (P.best_score - score) / P.best_score : 0.0;
   const bool qualifies = det > P.threshold || P.forced;                                               // learning.rs:160
   unsigned long long q_pen = 0, q_mild = 0;
   if (qualifies) {
-    if (lane == 0) atomicAdd(&st[2], mult);
+    if (lane == 0) atomicAdd(&st(2), mult);
     if (det < 0.0) {      // forced contrast on an episode that beats the best: powf(negative, 0.3) is NaN in the reference and
                           // (w * NaN).max(MIN_WEIGHT) == MIN_WEIGHT — in log space any exponent below -9.2 (eg_reduced_math.h)
       q_pen = q_mild = (unsigned long long)(long long)(rm::kLnNanPenalty * kQ32);
@@ -1605,17 +1609,18 @@ __device__ void episode_update_stats(const DevOut& O, const DevSnapshot& S, cons
       b0 = S.best_off()[y]; nb = S.best_off()[y + 1] - b0; d0 = S.bestd_off()[y]; nbd = S.bestd_off()[y + 1] - d0;
     }
     if (valid && qualifies) {
-      if (!((mask >> a) & 1ull)) atomicAdd(&st[8 + y * EG_N_ACTIONS + a], q_pen);
+      if (!((mask >> a) & 1ull)) atomicAdd(&st(8 + y * EG_N_ACTIONS + a), q_pen);
       else if (j < nb + nbd) {
         const int b = j < nb ? S.best_actions()[b0 + j] : S.bestd_actions()[d0 + (j - nb)];
-        if (a != b) atomicAdd(&st[8 + kStatsMain + y * EG_N_ACTIONS + a], q_mild);
+        if (a != b) atomicAdd(&st(8 + kStatsMain + y * EG_N_ACTIONS + a), q_mild);
       }
     }
     if (valid && j >= nr_y && !((dmask >> a) & 1ull)) {        // learning.rs:346-352
       const int slot = (a < kFirstOffset && a % 3 == 0) ? c_deficit_slot[a / 3] : (a == kNothing ? 14 : -1);
-      if (slot >= 0) atomicAdd(&st[8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot], mult);
+      if (slot >= 0) atomicAdd(&st(8 + 2 * kStatsMain + y * EG_N_DEFICIT + slot), mult);
     }
   }
+#undef st
 }
 
 #ifdef EG_STAMPS
@@ -1648,7 +1653,7 @@ struct EpisodeMap {
   // episodes once and k_replay_broadcast hands every one of them the record: the replay variants have nothing to do (0: no hoist)
   const unsigned long long* hoist;
   unsigned long long hoist_seq;
-  uint32_t stats_rep;         // 1: `stats` is kStatsReplicas copies of the statistics array; this workgroup adds to copy (index % kStatsReplicas)
+  uint32_t stats_rep;         // 1: `stats` is kStatsReplicas copies of the statistics array (entry-major); this workgroup adds to copy (index % kStatsReplicas)
 };
 __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b) {
   if (m.mode == 0u) return b;
@@ -2234,7 +2239,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     wave_sync();
     StatsParams P;      // only needed here: not held in registers through the episode
     load_stats_params(S, P);
-    episode_update_stats(O, S, P, e, lane, stats + (emap.stats_rep ? (size_t)(blockIdx.x % (uint32_t)kStatsReplicas) * EG_STATS_LEN : 0));
+    episode_update_stats(O, S, P, e, lane, stats, 1ull, emap.stats_rep ? (int)(blockIdx.x % (uint32_t)kStatsReplicas) : -1);
   }
 }
 
@@ -2821,7 +2826,7 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
       const DevOut scratch{p.coop_out, reinterpret_cast<double*>(p.coop_out + rec::stride)};
       hipExtLaunchKernelGGL(k_replay_coop, dim3(1), dim3(coop::kThreads), 0, (hipStream_t)p.stream_heavy, (hipEvent_t)p.ev[0], nullptr, 0,
                             t, s, scratch, p.hoist_seq, p.d_hoist);
-      hipLaunchKernelGGL(k_replay_books, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)p.stream_heavy, t, s, scratch, p.hoist_seq, p.d_hoist, d_stats, p.n_heavy);
+      hipLaunchKernelGGL(k_replay_books, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)p.stream_heavy, t, s, scratch, p.hoist_seq, p.d_hoist, d_stats, p.n_heavy, rep ? 1 : 0);
     }
     // (the short one first: when it is the one that returns at once it finds the chip empty and is gone in microseconds; a
     //  256-register wave of the long one, when IT has nothing to do, must wait until a SIMD full of lean waves has drained two
@@ -2850,21 +2855,27 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
   }
   return (int)hipGetLastError();
 }
-// The replicated statistics of a batch into its packet (sums; slot 3 is a maximum), and the copies cleared for the next batch.
+// The replicated statistics of a batch into its packet (sums; slot 3 is a maximum), and the copies cleared for the next batch: a wave
+// an entry — its 64 copies are one 512-byte line.
 __global__ void __launch_bounds__(256) k_fold_stats(long long* rep, long long* stats) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  static_assert(kStatsReplicas == kWave, "a lane a copy");
+  const int lane = threadIdx.x & (kWave - 1);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= EG_STATS_LEN) return;
-  unsigned long long acc = 0ull;
-  for (int r = 0; r < kStatsReplicas; ++r) {
-    const unsigned long long v = (unsigned long long)rep[(size_t)r * EG_STATS_LEN + i];
-    acc = i == 3 ? (v > acc ? v : acc) : acc + v;
-    rep[(size_t)r * EG_STATS_LEN + i] = 0;
+  unsigned long long v = (unsigned long long)rep[(size_t)i * kStatsReplicas + lane];
+  rep[(size_t)i * kStatsReplicas + lane] = 0;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) {
+    const unsigned long long o = (unsigned long long)__shfl_xor((long long)v, sh);
+    v = i == 3 ? (o > v ? o : v) : v + o;
   }
-  const unsigned long long old = (unsigned long long)stats[i];
-  stats[i] = (long long)(i == 3 ? (acc > old ? acc : old) : old + acc);
+  if (lane == 0) {
+    const unsigned long long old = (unsigned long long)stats[i];
+    stats[i] = (long long)(i == 3 ? (v > old ? v : old) : old + v);
+  }
 }
 int launch_fold_stats(long long* d_rep, long long* d_stats, void* stream) {
-  hipLaunchKernelGGL(k_fold_stats, dim3((EG_STATS_LEN + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_rep, d_stats);
+  hipLaunchKernelGGL(k_fold_stats, dim3((EG_STATS_LEN + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_rep, d_stats);
   return (int)hipGetLastError();
 }
 int launch_place(const DevTables& t, int gen_type, int year_index, const uint16_t* d_cells, int n_extra,
