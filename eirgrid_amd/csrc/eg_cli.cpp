@@ -44,6 +44,7 @@ struct Args {   // cli/cli.rs:5-59
   bool existing_operational_at_start = false;
   uint64_t stop_after = 0;      // leave the loop (as an interrupt would) once this many iterations are done and checkpointed
   std::string dump_world;       // write the loaded world (eirgrid_amd JSON form) there and exit: no device needed
+  bool replay_hoist = true;     // the replay iterations of a batch computed once (eg_replay_hoist): the same results, the replay phases 5x faster
 };
 
 void usage() {
@@ -59,7 +60,9 @@ void usage() {
             "      --batch <B>          iterations per GPU launch [default: 1024]\n      --update <sequential|reduced>  [default: reduced]\n"
             "      --device <N>         [default: 0]\n      --existing-operational-at-start\n"
             "      --stop-after <N>     stop like an interrupted run once N iterations are done and checkpointed (resume tests)\n"
-            "      --dump-world <FILE>  write the world as loaded (the --world JSON form) and exit; needs no GPU");
+            "      --dump-world <FILE>  write the world as loaded (the --world JSON form) and exit; needs no GPU\n"
+            "      --no-replay-hoist    run every replay iteration of a batch on its own (default: the replay iterations of a batch —\n"
+            "                           one and the same computation — are computed once; identical results either way)");
 }
 
 bool parse(int argc, char** argv, Args& a) {
@@ -96,6 +99,7 @@ bool parse(int argc, char** argv, Args& a) {
     else if (s == "--existing-operational-at-start") a.existing_operational_at_start = true;
     else if (s == "--stop-after") a.stop_after = std::strtoull(v().c_str(), nullptr, 10);
     else if (s == "--dump-world") a.dump_world = v();
+    else if (s == "--no-replay-hoist") a.replay_hoist = false;
     else if (s == "-h" || s == "--help") { usage(); std::exit(0); }
     else { std::fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage(); return false; }
   }
@@ -239,6 +243,10 @@ int main(int argc, char** argv) {
   const eg_world world = wd.view(a.existing_operational_at_start);
   eg_ctx* ctx = eg_create(a.device, &world);
   if (!ctx) { std::fprintf(stderr, "eg_create: %s\n", eg_last_error()); return 1; }
+  // The reference's replay phases (the last 10 % of a run, --force-full-simulation: core/multi_simulation.rs:38-39, :437-465) run the
+  // same replay in every iteration of a batch: computed once unless asked otherwise (worlds the hoist is not sized for: every
+  // iteration on its own, silently — the results are the same)
+  if (a.replay_hoist) (void)eg_replay_hoist(ctx, 1);
 
   // run directory and resume (multi_simulation.rs:160-165, :210-290, :396-404)
   eg_policy* policy = nullptr; uint64_t start_iteration = 0; std::string run_dir;

@@ -88,6 +88,38 @@ def test_config5_100k_iterations_checkpoint_and_resume(built, tmp_path):
     assert t_a1 + t_a2 < 120.0, "time budget of the 100k-iteration run (two legs) on one MI355X"
 
 
+def test_cli_run_is_the_same_with_and_without_the_replay_hoist(built, tmp_path):
+    """The driver computes the replay iterations of a batch once (the reference's replay phases run the same replay in every
+    iteration: core/multi_simulation.rs:38-39, :437-465); `--no-replay-hoist` runs every iteration on its own.  20 480 iterations
+    with a forced all-replay run (--force-full-simulation) and the ordinary schedule (replays in the last 10 %): the checkpoint, the
+    exported summary and the printed best result are the same bytes either way — and the hoisted all-replay run is the faster one."""
+    import hashlib
+    for extra in (("--force-full-simulation",), ()):
+        got = {}
+        for hoist in (True, False):
+            ck = str(tmp_path / f"ck_{len(extra)}_{int(hoist)}")
+            t0 = time.time()
+            out = subprocess.run([CLI, "--world", WORLD, "-n", "20480", "--batch", "1024", "-i", "4", "--seed", "11", "-c", ck, "-r", "1000", "--no-continue",
+                                  *extra, *(() if hoist else ("--no-replay-hoist",))], capture_output=True, text=True, timeout=900)
+            wall = time.time() - t0
+            assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+            rd, state = _state(ck)
+            files = {}      # every exported CSV, by its path below the export's time-stamped directory, without the lines that carry that stamp
+            stamp = os.listdir(os.path.join(rd, "enhanced_csv"))[0]
+            for base, _, names in os.walk(os.path.join(rd, "enhanced_csv", stamp)):
+                for nm in names:
+                    if nm.endswith(".csv") and nm != "improvement_history.csv":      # (its rows carry wall-clock stamps; the history itself is in `state`)
+                        text = [l for l in open(os.path.join(base, nm), encoding="utf-8").read().split("\n") if stamp not in l and "imestamp" not in l]
+                        files[os.path.relpath(os.path.join(base, nm), os.path.join(rd, "enhanced_csv", stamp))] = hashlib.sha256("\n".join(text).encode()).hexdigest()
+            # the printed best result, without the run's pace and directory
+            best = [re.sub(r"\d+ iterations/s", "", l) for l in out.stdout.splitlines() if ("Best" in l or "best" in l) and not l.startswith("Done:")]
+            got[hoist] = (state, files, best, wall)
+        assert got[True][0] == got[False][0], extra
+        assert got[True][1] == got[False][1] and got[True][1], extra
+        assert got[True][2] == got[False][2], extra
+        print(f"CLI {' '.join(extra) or '(default schedule)'}: {got[True][3]:.2f} s hoisted, {got[False][3]:.2f} s per iteration")
+
+
 def test_config4_131072_episodes_as_eight_shards(world):
     """One update from 131 072 episodes: 8 shards of 16 384 by global episode index (every 10th index replays the best
     strategy), each rolled out into its own 37 008-byte packet, ONE k_apply_update over the 8 packets — against the host
