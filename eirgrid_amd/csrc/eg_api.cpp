@@ -110,6 +110,7 @@ struct eg_ctx {
   unsigned long long hoist_seq = 0;
   HoistInfo* d_hoist = nullptr; uint8_t* d_coop = nullptr;
   uint64_t hoist_batches = 0;      // batches launched with the hoist armed (eg_replay_hoist_stats)
+  int coop_force = 0;              // EIRGRID_COOP_FORCE (test hook): the hoisted searches' rarely-run paths
   long long* d_stats_rep = nullptr;      // kStatsReplicas copies of the statistics array (RolloutPlan::d_stats_rep); EIRGRID_STATS_REPLICAS=0: none
 };
 
@@ -260,7 +261,7 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
     plan.d_stats_rep = (off || n < 4096u) ? nullptr : c->d_stats_rep;
   }
   if (c->hoist_on && plan.n_heavy > 0) {      // the replay episodes of this batch are computed once (eg_replay_coop.h)
-    plan.hoist_seq = ++c->hoist_seq; plan.d_hoist = c->d_hoist; plan.coop_out = c->d_coop;
+    plan.hoist_seq = ++c->hoist_seq; plan.d_hoist = c->d_hoist; plan.coop_out = c->d_coop; plan.coop_force = c->coop_force;
     c->hoist_batches += 1;
   }
   if (split) {
@@ -499,6 +500,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
       set_error("hipMalloc(replay hoist) failed"); rc = EG_ERR_HIP;
     }
     if (const char* rh = std::getenv("EIRGRID_REPLAY_HOIST")) c->hoist_on = c->hoist_supported && rh[0] == '1';
+    if (const char* cf = std::getenv("EIRGRID_COOP_FORCE")) c->coop_force = std::atoi(cf);
   }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;

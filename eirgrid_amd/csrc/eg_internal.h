@@ -299,6 +299,7 @@ struct RolloutPlan {
   unsigned long long hoist_seq;
   HoistInfo* d_hoist;
   uint8_t* coop_out;
+  int coop_force;      // test hook (EIRGRID_COOP_FORCE): 1 = every hoisted search evaluates its candidates exactly, 2 = every one is the exact scan
   // statistics epilogue: kStatsReplicas copies of the statistics array, entry-major — an episode adds to copy (workgroup index % kStatsReplicas) and
   // k_fold_stats folds the copies into the packet behind the batch.  16 384 episodes adding to the same few hundred addresses are
   // serialised address by address in L2: with the replay episodes hoisted that was 0.8 ms of a 1.9 ms batch (profiles/r04_ab_notes.log).

@@ -160,7 +160,8 @@ __device__ __forceinline__ int scan_fast(const double (&b)[kPer], int rc, int ti
 
 // ---- a search, slow path (several cells within reach of the maximum, or nothing decided): place_heavy's steps 2 and 3, then the
 //      exact scan.  `tb`: the lane's unpenalised scores.  Returns the cell, or -1: no candidate has a positive score. ----
-__device__ __forceinline__ int scan_slow(const DevTables& T, const double (&tb)[kPer], int yi, int t, int ngen, int tid, int lane, int wave) {
+// `skip_candidates` (test hook, EIRGRID_COOP_FORCE=2): go straight to the exact scan.
+__device__ __forceinline__ int scan_slow(const DevTables& T, const double (&tb)[kPer], int yi, int t, int ngen, int tid, int lane, int wave, bool skip_candidates) {
   const int info = __builtin_amdgcn_readfirstlane(sc.tinfo[t]);
   const int rc = (info >> 4) & 15, off = (int)((unsigned)info >> 24) << 1, cap = (info >> 16) & 255;
   const bool marine = ((info >> 8) & 1) != 0;
@@ -189,7 +190,7 @@ __device__ __forceinline__ int scan_slow(const DevTables& T, const double (&tb)[
     int total = 0, before = 0;
     for (int w = 0; w < kWaves; ++w) { const int c = sc.xcnt[w]; total += c; before += w < wave ? c : 0; }
     total = __builtin_amdgcn_readfirstlane(total);
-    if (M >= 1e-250 && total != 0 && total <= kWave) {
+    if (M >= 1e-250 && total != 0 && total <= kWave && !skip_candidates) {
       int pos = before;
 #pragma unroll
       for (int k = 0; k < kPer; ++k) {
@@ -410,7 +411,9 @@ __device__ __forceinline__ bool script(const DevTables& T, const DevSnapshot& S,
 }  // namespace coop
 
 // One workgroup: the batch's replay script and its placements, once.  `O`: the scratch record (episode 0 of it).
-__global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long hoist_seq, HoistInfo* info) {
+// `force` (test hook, EIRGRID_COOP_FORCE): 1 = every search takes the slow path (exact evaluation of the candidates), 2 = every search is the
+// exact scan of all cells — the rarely-run paths, held against the per-episode kernels and the oracle by tests/test_gpu_replay_hoist.py.
+__global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long hoist_seq, HoistInfo* info, int force) {
   using namespace coop;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -494,6 +497,7 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
       default: cell = scan_fast(base[0], rc, tid, lane, wave EG_CS_PASS); break;
     }
     EG_CS(7);      // 7: searches: the decision
+    if (force != 0) cell = -2;
     if (cell == -2) {      // several cells within reach of the maximum, or nothing decided (rare)
       double tb[kPer];
 #pragma unroll
@@ -501,7 +505,7 @@ __global__ void __launch_bounds__(coop::kThreads, 1) k_replay_coop(DevTables T, 
 #pragma unroll
       for (int vv = 1; vv < kVariants; ++vv)
         if (vv == v) { _Pragma("unroll") for (int k = 0; k < kPer; ++k) tb[k] = base[vv][k]; }
-      cell = scan_slow(T, tb, yi, t, g, tid, lane, wave);
+      cell = scan_slow(T, tb, yi, t, g, tid, lane, wave, force == 2);
       slow += 1;
     }
     if (cell < 0) { failed = true; break; }      // EG_EP_NO_LOCATION: the per-episode path reports it

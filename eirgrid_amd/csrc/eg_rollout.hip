@@ -2825,7 +2825,7 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
       }
       const DevOut scratch{p.coop_out, reinterpret_cast<double*>(p.coop_out + rec::stride)};
       hipExtLaunchKernelGGL(k_replay_coop, dim3(1), dim3(coop::kThreads), 0, (hipStream_t)p.stream_heavy, (hipEvent_t)p.ev[0], nullptr, 0,
-                            t, s, scratch, p.hoist_seq, p.d_hoist);
+                            t, s, scratch, p.hoist_seq, p.d_hoist, p.coop_force);
       hipLaunchKernelGGL(k_replay_books, dim3(EG_YEARS), dim3(kWave), 0, (hipStream_t)p.stream_heavy, t, s, scratch, p.hoist_seq, p.d_hoist, d_stats, p.n_heavy, rep ? 1 : 0);
     }
     // (the short one first: when it is the one that returns at once it finds the chip empty and is gone in microseconds; a

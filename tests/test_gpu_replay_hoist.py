@@ -212,3 +212,41 @@ def test_training_loops_with_and_without_the_hoist_hold_the_same_policy(world):
             finally:
                 eng.close()
         assert states[0] == states[1], (episodes, fraction)
+
+
+def test_the_rarely_run_paths_of_the_hoisted_search(world):
+    """A hoisted search decides by one exchange when a single cell holds the maximum; several cells within reach of it are evaluated
+    exactly (the reference's product in list order), and subnormal ranges / more than 64 such cells / no positive score take the exact
+    scan of all cells.  EIRGRID_COOP_FORCE = 1 / 2 sends EVERY search down the second / third path: same bytes as the per-episode
+    kernels for lists of ~140 and ~600 generators, other options (no energy sales, no yearly rows) and another world included."""
+    from eirgrid_amd.world import synthetic_world
+    rng = np.random.default_rng(777)
+    other = synthetic_world(seed=0xE16D0003)
+    for wld, kwargs in ((world, {}), (world, {"enable_energy_sales": False, "write_yearly": False}), (other, {})):
+        policies = [_full_script(rng, 5, [0, 4, 12, 7, 1], offsets_per_year=1), _full_script(rng, 23, [0, 4, 12, 7, 5, 13, 9], offsets_per_year=2)]
+        plain = Engine(wld, device=0)
+        forced = {}
+        for f in ("0", "1", "2"):
+            os.environ["EIRGRID_COOP_FORCE"] = f
+            try:
+                forced[f] = Engine(wld, device=0)
+            finally:
+                del os.environ["EIRGRID_COOP_FORCE"]
+            forced[f].replay_hoist(True)
+        try:
+            for k, pol in enumerate(policies):
+                n = 40
+                mask = (np.arange(n) % 4 == 1).astype(np.uint8)
+                a = plain.rollout_batch(pol, 55 + k, n, replay_mask=mask, **kwargs)
+                assert (a.status == 0).all()
+                for f, eng in forced.items():
+                    b = eng.rollout_batch(pol, 55 + k, n, replay_mask=mask, **kwargs)
+                    for name in _ALL_FIELDS:
+                        if name == "yearly" and not kwargs.get("write_yearly", True):
+                            continue
+                        assert _used(a, name).tobytes() == _used(b, name).tobytes(), (f, k, name, kwargs)
+                    assert eng.replay_hoist_stats()[1], (f, k)
+        finally:
+            plain.close()
+            for eng in forced.values():
+                eng.close()

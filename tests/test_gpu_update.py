@@ -186,6 +186,15 @@ def test_two_rank_bench_rehearsal_at_the_real_shard_size():
     assert cfg["last_batch"]["replay_episodes"] in (1638, 1639) and cfg["last_batch"]["generators_per_replay_episode"] > 100
     assert len(cfg["replica_digests"]) == 2 and len(set(cfg["replica_digests"])) == 1, cfg["replica_digests"]
     assert line["value"] > 0 and line["scaling"] == "weak"
+    # the same batches with the replay hoist on, and the state the 2-rank loop itself reaches (grown at 2 x 16 384 per update on
+    # every rank, timed with the exchange in the loop): both paths, nobody fails
+    h = line["config2_replay_hoisted"]
+    assert h["hoist_served_last_batch"] and h["episodes_failed"] == 0 and h["value"] > 0
+    sn = line["sustained_at_n"]
+    for key in ("per_episode_replays", "replay_hoisted"):
+        assert sn[key]["value"] > 0 and sn[key]["episodes_failed"] == 0 and sn[key]["last_batch"]["ok"] == 16384
+    assert sn["replay_hoisted"]["hoist_served_last_batch"]
+    assert sn["per_episode_replays"]["replay"] == sn["replay_hoisted"]["replay"] and sn["replay_hoisted"]["replay"]["best_list_len"] > 96
 
 
 def test_bench_line_contract_on_one_gpu():
