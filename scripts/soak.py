@@ -3,7 +3,8 @@
 Every trial draws a random policy (perturbed tables, stall, rates, random best lists — every fourth trial long ones, so that
 the replay episodes place hundreds of generators, every sixteenth 20-40 additions per year: 500-1 000 generators per replay
 episode, beyond the 512 the kernels keep in LDS), runs 1,536 episodes through BOTH kernels (helper-wave and single-wave),
-and through an engine without the penalty-field pool (every search the exact scan), and demands identical bytes, checks 48
+through an engine without the penalty-field pool (every search the exact scan) and through two engines with the replay hoist on (as it
+decides, and with every hoisted search forced down its slow path), and demands identical bytes, checks 48
 random episodes against the tabled CPU oracle bit for bit, and then takes 6 training steps on the device and on the host
 from that policy and demands identical policies, and the independent restatement of the batch update within 1e-12 of them.
 Exit code 0 = everything matched."""
@@ -24,6 +25,13 @@ for mode in ("0", "all"):
 os.environ["EIRGRID_HELPER_WAVES"] = "0"; os.environ["EIRGRID_HEAVY_SLOTS"] = "0"
 engines["exact"] = Engine(world, device=0)
 del os.environ["EIRGRID_HELPER_WAVES"]; del os.environ["EIRGRID_HEAVY_SLOTS"]
+# the replay hoist (eg_replay_hoist): the replay episodes of a batch computed once — as it decides by itself, and with every hoisted
+# search forced down its slow path (EIRGRID_COOP_FORCE=1: exact evaluation of the candidates)
+engines["hoist"] = Engine(world, device=0); engines["hoist"].replay_hoist(True)
+os.environ["EIRGRID_COOP_FORCE"] = "1"
+engines["hoist_slow"] = Engine(world, device=0); engines["hoist_slow"].replay_hoist(True)
+del os.environ["EIRGRID_COOP_FORCE"]
+served = 0
 dev = Engine(world, device=0)
 tb = O.OracleTables(HostTables(world), len(world.existing_x))
 rng = np.random.default_rng(int(time.time()) if len(sys.argv) > 2 else 20261004)
@@ -37,6 +45,8 @@ for trial in range(trials):
         lo, hi = (20, 41) if trial % 16 == 15 else (5, 15)
         run = [[int(3 * rng.choice(types) + rng.integers(0, 3)) for _ in range(int(rng.integers(lo, hi)))] for _ in range(26)]
     dfl = [(3 * rng.choice([8, 7, 12, 11, 9, 0, 1, 4, 10, 5, 2, 3, 13, 14], int(rng.choice([0, 1, 2, 3])))).tolist() for _ in range(26)]
+    if trial % 2 == 1:      # a script a replay can follow to its end without a fallback draw (four repair actions a year): the hoist takes it
+        dfl = [[int(rng.choice([3 * 8, 3 * 7, 3 * 12, 3 * 11, 3 * 0, 48, 60])) for _ in range(4)] for _ in range(26)]
     nr = np.array([len(l) for l in run], np.int32); nd = np.array([len(l) for l in dfl], np.int32)
     pol.apply_episode([float(rng.choice([-5e4, 3e5])), 0.7, float(rng.choice([4e10, 9e11])), 1.0], nr,
                       np.array([a for l in run for a in l], np.uint8), nd, np.array([a for l in dfl for a in l], np.uint8))
@@ -55,6 +65,14 @@ for trial in range(trials):
     for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
         assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (trial, name)
         assert getattr(a, name).tobytes() == getattr(c, name).tobytes(), (trial, name, "field path vs exact scan")
+    for key in ("hoist", "hoist_slow"):
+        h = engines[key].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
+        for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
+            assert getattr(a, name).tobytes() == getattr(h, name).tobytes(), (trial, name, key)
+        for name, cnt in (("gen_cell", a.n_gens), ("gen_pack", a.n_gens), ("off_pack", a.n_offsets), ("run_log", a.n_run.sum(axis=1)), ("def_log", a.n_def.sum(axis=1)), ("act_log", a.n_act.sum(axis=1))):
+            lv = np.arange(getattr(a, name).shape[1])[None, :] < cnt[:, None]
+            assert (getattr(a, name)[lv] == getattr(h, name)[lv]).all(), (trial, name, key)
+    served += int(engines["hoist"].replay_hoist_stats()[1])
     live = np.arange(a.gen_cell.shape[1])[None, :] < a.n_gens[:, None]      # (the buffers are not cleared between batches)
     for name in ("gen_cell", "gen_pack"):
         assert (getattr(a, name)[live] == getattr(b, name)[live]).all() and (getattr(a, name)[live] == getattr(c, name)[live]).all(), (trial, name)
@@ -88,4 +106,4 @@ for trial in range(trials):
         assert x.tobytes() == y.tobytes(), (trial, "device vs host policy")
     assert host.lists(0) == devp.lists(0) and host.get("iterations_without_improvement") == devp.get("iterations_without_improvement")
     print(f"trial {trial:3d} ok  ({time.time() - t0:.0f} s; failed episodes in batch: {int((a.status != 0).sum())}; most generators in an episode {int(a.n_gens.max())})", flush=True)
-print("soak: all", trials, "trials matched")
+print("soak: all", trials, "trials matched; the replay hoist served", served, "of them (the others needed a fallback draw or hit a capacity)")
