@@ -112,6 +112,9 @@ struct eg_ctx {
   uint64_t hoist_batches = 0;      // batches launched with the hoist armed (eg_replay_hoist_stats)
   int coop_force = 0;              // EIRGRID_COOP_FORCE (test hook): the hoisted searches' rarely-run paths
   long long* d_stats_rep = nullptr;      // kStatsReplicas copies of the statistics array (RolloutPlan::d_stats_rep); EIRGRID_STATS_REPLICAS=0: none
+  // per-episode replay kernel (eg_replay_solo.h; EIRGRID_REPLAY_SOLO=0: off): a word per replay episode of a launch, the launches' sequence
+  unsigned long long* d_solo = nullptr; uint32_t solo_cap = 0; unsigned long long solo_seq = 0;
+  bool solo_on = true;
 };
 
 namespace {
@@ -259,6 +262,20 @@ int launch_batch(eg_ctx* c, uint64_t seed, uint64_t first_index, uint32_t n, con
     // (small batches add directly: a few hundred episodes do not queue up in L2, and the fold is a launch of its own — configs[1],
     //  1 024 episodes: 0.257 ms per batch without it, 0.264 with)
     plan.d_stats_rep = (off || n < 4096u) ? nullptr : c->d_stats_rep;
+  }
+  // long replay episodes: script / placements / rows, each on its own wave (eg_replay_solo.h) — unless the batch's replays are computed
+  // once anyway (what ends that script ends this one as well: the classic variant alone is the fallback then)
+  if (plan.n_heavy > 0 && !plan.helper_waves && !plan.skip_long && !c->hoist_on) {
+    if (c->solo_on) {
+      if (plan.n_heavy > c->solo_cap) {
+        if (c->d_solo) (void)hipFree(c->d_solo);
+        c->d_solo = nullptr; c->solo_cap = 0;
+        EG_HIP(hipMalloc((void**)&c->d_solo, sizeof(unsigned long long) * plan.n_heavy));
+        EG_HIP(hipMemsetAsync(c->d_solo, 0, sizeof(unsigned long long) * plan.n_heavy, nullptr));
+        c->solo_cap = plan.n_heavy;
+      }
+      plan.solo_seq = ++c->solo_seq; plan.d_solo = c->d_solo;
+    }
   }
   if (c->hoist_on && plan.n_heavy > 0) {      // the replay episodes of this batch are computed once (eg_replay_coop.h)
     plan.hoist_seq = ++c->hoist_seq; plan.d_hoist = c->d_hoist; plan.coop_out = c->d_coop; plan.coop_force = c->coop_force;
@@ -501,6 +518,7 @@ eg_ctx* eg_create(int32_t device_ordinal, const eg_world* world) {
     }
     if (const char* rh = std::getenv("EIRGRID_REPLAY_HOIST")) c->hoist_on = c->hoist_supported && rh[0] == '1';
     if (const char* cf = std::getenv("EIRGRID_COOP_FORCE")) c->coop_force = std::atoi(cf);
+    if (const char* so = std::getenv("EIRGRID_REPLAY_SOLO")) c->solo_on = so[0] != '0';
   }
   if (rc != EG_OK) { eg_destroy(c); return nullptr; }
   return c;
@@ -516,6 +534,7 @@ void eg_destroy(eg_ctx* c) {
   if (c->d_fold) (void)hipFree(c->d_fold);
   if (c->d_hoist) (void)hipFree(c->d_hoist);
   if (c->d_stats_rep) (void)hipFree(c->d_stats_rep);
+  if (c->d_solo) (void)hipFree(c->d_solo);
   if (c->d_coop) (void)hipFree(c->d_coop);
   if (c->h_snap) (void)hipHostFree(c->h_snap);
   if (c->h_list_len) (void)hipHostFree(c->h_list_len);

@@ -304,6 +304,10 @@ struct RolloutPlan {
   // k_fold_stats folds the copies into the packet behind the batch.  16 384 episodes adding to the same few hundred addresses are
   // serialised address by address in L2: with the replay episodes hoisted that was 0.8 ms of a 1.9 ms batch (profiles/r04_ab_notes.log).
   long long* d_stats_rep;
+  // per-episode replay kernel (eg_replay_solo.h): solo_seq != 0 = k_replay_solo runs ahead of the long-replay variant and marks what it
+  // has completed in d_solo (a word per workgroup of the replay grid)
+  unsigned long long solo_seq;
+  unsigned long long* d_solo;
 };
 constexpr int kStatsReplicas = 64;
 int launch_fold_stats(long long* d_rep, long long* d_stats, void* stream);

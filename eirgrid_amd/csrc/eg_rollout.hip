@@ -1654,6 +1654,10 @@ struct EpisodeMap {
   const unsigned long long* hoist;
   unsigned long long hoist_seq;
   uint32_t stats_rep;         // 1: `stats` is kStatsReplicas copies of the statistics array (entry-major); this workgroup adds to copy (index % kStatsReplicas)
+  // per-episode replay kernel (eg_replay_solo.h): word b carries solo_seq when k_replay_solo has completed workgroup b's episode — the
+  // long-replay variant, launched behind it, then has nothing to do for that episode (0 / null: no such kernel in this launch)
+  unsigned long long* solo;
+  unsigned long long solo_seq;
 };
 __device__ __forceinline__ uint32_t map_episode(const EpisodeMap& m, uint32_t b) {
   if (m.mode == 0u) return b;
@@ -1703,6 +1707,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
     const bool long_list = S_in.state()->has_lists && S_in.best_off()[EG_YEARS] > kShortReplayMax;
     if (long_list != kHeavy) return;
     if (emap.hoist_seq != 0ull && *emap.hoist == emap.hoist_seq) return;      // served by k_replay_coop / k_replay_broadcast
+    if constexpr (kHeavy) if (emap.solo_seq != 0ull && emap.solo[blockIdx.x] == emap.solo_seq) return;      // done by k_replay_solo
   }
   const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
@@ -2257,6 +2262,11 @@ __global__ void __launch_bounds__(kWave, 7) k_heavy_register_budget(unsigned lon
 }
 #endif
 
+#include "eg_replay_script.h"      // a replay episode's script and yearly rows (both objects)
+#ifdef EG_TU_THROUGHPUT
+#include "eg_replay_solo.h"        // k_replay_solo: a long replay episode on its own wave, script / placements / rows one after the other
+#endif
+
 #ifndef EG_TU_THROUGHPUT      // (everything from here to the launchers lives in eg_rollout.o only)
 #include "eg_replay_coop.h"      // k_replay_coop, k_replay_broadcast: the replay episodes of a batch, computed once
 
@@ -2767,18 +2777,26 @@ __global__ void __launch_bounds__(1024) k_apply_update(uint8_t* snap_base, const
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
                               const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
-                              uint32_t stats_rep, void* stream, void* ev0, void* ev1);
+                              uint32_t stats_rep, unsigned long long* solo, unsigned long long solo_seq, void* stream, void* ev0, void* ev1);
 #ifdef EG_TU_THROUGHPUT
 int launch_rollout_throughput(int kind, const DevTables& t, const DevSnapshot& s, const DevOut& o, uint64_t seed, uint64_t first_index, uint32_t n,
                               const uint8_t* d_replay_mask, uint32_t replay_period, long long* d_stats, uint32_t count, uint32_t mode,
                               const uint32_t* index, uint32_t off, uint32_t period, const unsigned long long* hoist, unsigned long long hoist_seq,
-                              uint32_t stats_rep, void* stream, void* ev0, void* ev1) {
+                              uint32_t stats_rep, unsigned long long* solo, unsigned long long solo_seq, void* stream, void* ev0, void* ev1) {
   EpisodeMap map{};
   map.count = count; map.mode = mode; map.index = index; map.off = off; map.period = period; map.hoist = hoist; map.hoist_seq = hoist_seq; map.stats_rep = stats_rep;
+  map.solo = solo; map.solo_seq = solo_seq;
   // the timing events ride on the dispatch packet itself (no separate barrier packets around the kernel)
 #define EG_LAUNCH_TP(kKind) hipExtLaunchKernelGGL((k_rollout<0, kKind>), dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0, \
                                                   t, s, o, (unsigned long long)seed, (unsigned long long)first_index, n, d_replay_mask, replay_period, d_stats, map)
-  if (kind == kReplayLong) EG_LAUNCH_TP(kReplayLong);
+  if (kind == kReplayLong) {
+    // every long replay episode on its own wave, script / placements / rows one after the other (eg_replay_solo.h); the classic variant
+    // behind it runs what that kernel left undone (a script that needs a seeded draw or hits a capacity) and carries the stop event
+    if (solo_seq != 0ull)
+      hipLaunchKernelGGL(k_replay_solo, dim3(map.count), dim3(kWave), 0, (hipStream_t)stream, t, s, o, (unsigned long long)first_index, n, d_replay_mask, replay_period,
+                         d_stats, map);
+    EG_LAUNCH_TP(kReplayLong);
+  }
   else if (kind == kReplayShort) EG_LAUNCH_TP(kReplayShort);
   else EG_LAUNCH_TP(kLean);
 #undef EG_LAUNCH_TP
@@ -2795,7 +2813,7 @@ void launch_variant(bool helper_waves, const DevTables& t, const DevSnapshot& s,
                           d_replay_mask, replay_period, d_stats, map);
   else
     (void)launch_rollout_throughput(kKind, t, s, o, seed, first_index, n, d_replay_mask, replay_period, d_stats, map.count, map.mode, map.index, map.off, map.period,
-                                    map.hoist, map.hoist_seq, map.stats_rep, stream, ev0, ev1);
+                                    map.hoist, map.hoist_seq, map.stats_rep, map.solo, map.solo_seq, stream, ev0, ev1);
 }
 }  // namespace
 
@@ -2812,6 +2830,7 @@ int launch_rollout(const DevTables& t, const DevSnapshot& s, const DevOut& o, ui
     if (p.n_lean == 0) m.mode = 0u;
     else if (p.mode == 1u) { m.mode = 1u; m.index = p.d_index; }
     else { m.mode = 2u; m.off = p.off; m.period = p.period; }
+    if (!p.helper_waves && p.solo_seq != 0ull) { m.solo = p.d_solo; m.solo_seq = p.solo_seq; }
     const bool hoist = p.hoist_seq != 0ull;
     if (hoist) {
       // Replay hoist: ONE workgroup computes the batch's replay script and its placements (k_replay_coop, four waves with the whole
