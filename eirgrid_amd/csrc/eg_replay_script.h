@@ -267,4 +267,83 @@ __device__ __forceinline__ YearRow books_year(const DevTables& T, const DevSnaps
   return r;
 }
 
+// ---- the same rows, four years at a time (one wave: row r of its 64 lanes folds year y0 + r, sixteen list entries a step).  A year's
+//      sums are chains of dependent additions — one v_fmac_f64_dpp per list entry and sum, sixteen lanes wide —, so one year at a time
+//      three quarters of the wave idle through every chain; the years do not depend on each other, and a DPP row operation runs the
+//      four rows' chains side by side.  `g_end` / `o_end`: the lists' lengths at the end of each year (non-decreasing).  A row past the
+//      last year repeats it and writes nothing.  Every lane returns its row's year. ----
+template <class Load>
+__device__ __forceinline__ YearRow books_quad(const DevTables& T, const DevSnapshot& S_in, const DevOut& O, uint32_t e, int y0, const int* g_end, const int* o_end,
+                                              int lane, Load&& u16_at) {
+  const uint16_t* gen_cell = O.gen_cell(e); const uint16_t* gen_pack = O.gen_pack(e); const uint16_t* off_pack = O.off_pack(e);
+  const int j = lane & 15, yr = y0 + (lane >> 4);
+  const bool live = yr < kYears;
+  const int yi = live ? yr : kYears - 1;
+  const int ylast = y0 + 3 < kYears ? y0 + 3 : kYears - 1;
+  const int G = g_end[yi], NO = o_end[yi];
+  const int Gmax = __builtin_amdgcn_readfirstlane(g_end[ylast]), NOmax = __builtin_amdgcn_readfirstlane(o_end[ylast]);
+  double gcost = 0.0, gprev = 0.0, optot = T.pre_optot()[yi], co2 = T.pre_co2()[yi];
+  double tg = T.pre_tg()[yi], ig = T.pre_ig()[yi], sg = T.pre_sg()[yi];
+  const double* ccy = T.cc() + (unsigned)yi * kTypes * kYears * kMults * 2;
+  const double* ccp = T.cc() + (unsigned)(yi > 0 ? yi - 1 : 0) * kTypes * kYears * kMults * 2;
+  struct GT { double c, o, p, e, x0, x1, x2; };
+  auto gterms = [&](int i) -> GT {
+    GT r = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (i >= G) return r;
+    const int pk = u16_at(gen_pack, i), ty = pk & 15, b = (pk >> 4) & 31, m = pk >> 9;
+    const unsigned at = ((unsigned)(ty * kYears + b) * kMults + m) * 2;
+    const double2 cc = *reinterpret_cast<const double2*>(ccy + at);
+    r.c = cc.x;
+    r.o = (T.m03()[u16_at(gen_cell, i)] + T.t12()[(unsigned)yi * kTypes + ty]) + cc.y;
+    r.p = yi > 0 ? ccp[at] : 0.0;
+    r.e = T.co2_t()[ty];
+    const int cls = T.cls()[ty]; const double out = T.out_mw()[ty];
+    r.x0 = (cls != 1 && cls != 2) ? out : 0.0; r.x1 = cls == 1 ? out : 0.0; r.x2 = cls == 2 ? out : 0.0;
+    return r;
+  };
+  GT x = gterms(j);
+  for (int base = 0; base < Gmax; base += 16) {      // (a row whose year's list has ended adds +0.0: sums of non-negative terms)
+    const GT c = x;
+    x = gterms(base + 16 + j);      // the next step's terms are requested before this step is folded
+    fold2_row16(gcost, c.c, optot, c.o); fold2_row16(gprev, c.p, co2, c.e); fold2_row16(tg, c.x0, ig, c.x1);
+    sg = fold_row16(sg, c.x2);
+  }
+  double offs = 0.0, ocost = 0.0, oprev = 0.0;
+  for (int base = 0; base < NOmax; base += 16) {
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (base + j < NO) {
+      const int p = u16_at(off_pack, base + j), ot = p & 15, b = (p >> 4) & 31, m = p >> 9;
+      x0 = T.offv()[((unsigned)yi * kOffsetTypes + ot) * kYears + b];
+      x1 = T.offc()[((unsigned)yi * kOffsetTypes + ot) * kMults + m];
+      x2 = yi > 0 ? T.offc()[((unsigned)(yi - 1) * kOffsetTypes + ot) * kMults + m] : 0.0;
+    }
+    fold2_row16(offs, x0, ocost, x1);
+    oprev = fold_row16(oprev, x2);
+  }
+  Agg a;
+  a.co2 = co2; a.tg = tg; a.ig = ig; a.sg = sg; a.optot = optot; a.gcost = gcost; a.ocost = ocost; a.gcost_prev = gprev; a.ocost_prev = oprev;
+  a.offs = offs; a.usage = T.usage()[yi]; a.opcnt = T.pre_opcnt()[yi] + G;
+  const State s = state_of(a);
+  const double gen = (a.tg + a.ig) + a.sg;
+  const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * T.carbon_price()[yi];
+  const double total_capital = a.gcost + a.ocost;
+  const double yearly_capital = yi == 0 ? total_capital : total_capital - (a.gcost_prev + a.ocost_prev);
+  double sales = 0.0;
+  if (S_in.enable_energy_sales && s.balance > 0.0) { const double gwh = s.balance * 8.76; sales = gwh * 50000.0; }
+  const double yearly_total = yearly_capital + 0.0 + 0.0 - credit - (S_in.enable_energy_sales ? sales : 0.0);
+  if (j == 0 && live && S_in.write_yearly) {
+    double* row = O.yearly(e) + yi * EG_YEARLY_FIELDS;
+    row[EG_Y_YEAR] = (double)(2025 + yi); row[EG_Y_POP] = T.population()[yi]; row[EG_Y_USAGE] = a.usage; row[EG_Y_GEN] = gen;
+    row[EG_Y_BALANCE] = s.balance; row[EG_Y_OPINION] = s.opinion; row[EG_Y_YEARLY_CAPITAL] = yearly_capital;
+    row[EG_Y_TOTAL_CAPITAL] = total_capital; row[EG_Y_INFLATION] = T.inflation()[yi]; row[EG_Y_CO2] = a.co2;
+    row[EG_Y_OFFSET] = a.offs; row[EG_Y_NET_CO2] = s.net; row[EG_Y_YEARLY_CREDIT] = credit;
+    row[EG_Y_YEARLY_SALES] = sales; row[EG_Y_ACTIVE_GENS] = (double)a.opcnt;
+    row[EG_Y_UPGRADE_COSTS] = 0.0; row[EG_Y_CLOSURE_COSTS] = 0.0;
+    row[EG_Y_YEARLY_TOTAL_COST] = yearly_total;
+  }
+  YearRow r;
+  r.v[0] = yearly_total; r.v[1] = credit; r.v[2] = sales; r.v[3] = s.net; r.v[4] = s.opinion; r.v[5] = total_capital; r.v[6] = s.balance;
+  return r;
+}
+
 }  // namespace rs

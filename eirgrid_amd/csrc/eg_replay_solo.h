@@ -10,7 +10,7 @@
 //   2. its placements, one after the other, with k_rollout's own searches (place_search / place_heavy / place_exact_long, the penalty
 //      field of the pool, the lists' window in LDS and their tail in the record — the same code, so the same cells and the same
 //      accounting of requested chunks),
-//   3. its yearly rows (rs::books_year, a year after the other), the running totals, the header and the statistics epilogue.
+//   3. its yearly rows (rs::books_quad, four years at a time), the running totals, the header and the statistics epilogue.
 // An episode whose script cannot be finished without a seeded draw or a capacity, or that finds no location, publishes nothing:
 // k_rollout<0, kReplayLong>, launched behind this kernel, runs every episode whose word in `done` does not carry the batch's sequence
 // number — from the start, into the same record.
@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
 #define EG_SS(slot) do {} while (0)
 #endif
   load_static_tables(T, lane, true);
+#if defined(EG_SOLO_STAMPS) && defined(EG_STAMPS)
+  if (lane < 8) sm.hdbg[lane >> 2][lane & 3] = 0ull;
+#endif
   wave_sync();
   EG_SS(0);      // 0: set-up
 
@@ -146,22 +149,28 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   wave_sync();
   double total_cost = 0.0, total_credit = 0.0, total_sales = 0.0;
-  rs::YearRow last = {};
-  for (int yi = 0; yi < kYears; ++yi) {
-    const int G = __builtin_amdgcn_readfirstlane(words[yi]), NO = __builtin_amdgcn_readfirstlane(words[EG_YEARS + yi]);
-    last = rs::books_year(T, S_in, O, e, yi, G, NO, lane, [](const uint16_t* list, int i) { return tail_u16((unsigned long long)list, i); });
-    total_cost = yi == 0 ? last.v[0] : total_cost + last.v[0];
-    total_credit = yi == 0 ? last.v[1] : total_credit + last.v[1];
-    total_sales = yi == 0 ? last.v[2] : total_sales + last.v[2];
-    if (S_in.write_yearly && lane == 0) {
-      double* row = O.yearly(e) + yi * EG_YEARLY_FIELDS;
-      row[EG_Y_TOTAL_COST] = total_cost; row[EG_Y_TOTAL_CREDIT] = total_credit; row[EG_Y_TOTAL_SALES] = total_sales;
+  double last[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int y0 = 0; y0 < kYears; y0 += 4) {      // four years at a time, a row of sixteen lanes a year (rs::books_quad)
+    const rs::YearRow q = rs::books_quad(T, S_in, O, e, y0, words, words + EG_YEARS, lane, [](const uint16_t* list, int i) { return tail_u16((unsigned long long)list, i); });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yi = y0 + r;
+      if (yi >= kYears) break;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) last[k] = readlane_f64(q.v[k], 16 * r);
+      total_cost = yi == 0 ? last[0] : total_cost + last[0];
+      total_credit = yi == 0 ? last[1] : total_credit + last[1];
+      total_sales = yi == 0 ? last[2] : total_sales + last[2];
+      if (S_in.write_yearly && lane == 0) {
+        double* row = O.yearly(e) + yi * EG_YEARLY_FIELDS;
+        row[EG_Y_TOTAL_COST] = total_cost; row[EG_Y_TOTAL_CREDIT] = total_credit; row[EG_Y_TOTAL_SALES] = total_sales;
+      }
     }
   }
   EG_SS(5);      // 5: the yearly rows
   if (lane == 0) {      // SimulationMetrics, iteration.rs:69-74 (Q2: total_cost is the last year's capital cost)
-    O.metrics(e)[0] = last.v[3]; O.metrics(e)[1] = last.v[4]; O.metrics(e)[2] = last.v[5];
-    O.metrics(e)[3] = last.v[6] >= 0.0 ? 1.0 : 0.0;
+    O.metrics(e)[0] = last[3]; O.metrics(e)[1] = last[4]; O.metrics(e)[2] = last[5];
+    O.metrics(e)[3] = last[6] >= 0.0 ? 1.0 : 0.0;
     *O.status(e) = EG_EP_OK; *O.n_gens(e) = words[55]; *O.n_offsets(e) = words[56];
     *O.n_draws(e) = 0ull;      // (a replay that needs no fallback draws nothing)
     *O.bytes_moved(e) = (double)*reinterpret_cast<const unsigned long long*>(words + 58);
@@ -180,6 +189,9 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
   if (lane == 0) {      // (diagnostic build only: the cycle counts go to the otherwise unread tail of this episode's act_log buffer)
     unsigned long long* dbg = (unsigned long long*)(O.act_log(e) + EG_ACT_CAP - 256);
     for (int i = 0; i < 8; ++i) dbg[i] = cs[i];
+#ifdef EG_STAMPS      // (with -DEG_STAMPS as well: place_heavy's own counters — scan / candidates / exact evaluation cycles; chunks, candidates, searches)
+    for (int i = 0; i < 3; ++i) { dbg[8 + i] = sm.hdbg[0][i]; dbg[11 + i] = sm.hdbg[1][i]; }
+#endif
   }
 #endif
   if (lane == 0) emap.solo[blockIdx.x] = emap.solo_seq;      // (k_rollout<0, kReplayLong> is stream-ordered behind this kernel)

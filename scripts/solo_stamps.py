@@ -24,10 +24,15 @@ mask = np.zeros(n, np.uint8); mask[:n_rep] = 1
 for _ in range(2):
     res = eng.rollout_batch(pol, 321, n, replay_mask=mask)
 ms, k = eng.timing_read()
-st = res.act_log[:n_rep, -256:].copy().view(np.uint64).astype(np.float64)[:, :8]
-tot = st.sum(axis=1).mean()
+full = res.act_log[:n_rep, -256:].copy().view(np.uint64).astype(np.float64)
+st = full[:, :8]
+tot = st[:, :7].sum(axis=1).mean()
 g = res.n_gens[:n_rep].mean()
 print(f"{n_rep} replay episodes of {g:.0f} generators beside {n_lean} sampled ones, status ok {int((res.status == 0).sum())} of {n}; mean episode cycles {tot:.0f}")
 for name, col, per in (("set-up", 0, 1), ("script", 1, 1), ("placements: list entry", 2, g), ("placements: search", 3, g), ("placements: field update + list entry", 4, g),
                        ("yearly rows", 5, 26), ("header + statistics epilogue", 6, 1)):
     print(f"  {name:40s} {st[:, col].mean():12.0f} cycles {100 * st[:, col].mean() / tot:5.1f} %   ({st[:, col].mean() / per:.0f} each)")
+if full[:, 13].mean() > 0:      # built with -DEG_STAMPS as well: place_heavy's own counters
+    n = full[:, 13].mean()
+    print(f"  place_heavy: {n:.0f} searches per episode: scan {full[:, 8].mean() / n:.0f} cycles, candidates {full[:, 9].mean() / n:.0f}, exact evaluation + rest {full[:, 10].mean() / n:.0f}; "
+          f"chunks scanned per search {full[:, 11].mean() / n:.1f}, candidates {full[:, 12].mean() / n:.2f}")
