@@ -139,7 +139,7 @@ def sq_counters(workload: str):
     out = {"valu_busy": busy, "profile": name, "valu_insts_per_episode": run.get("SQ_INSTS_VALU", 0.0) / eps,
            "salu_insts_per_episode": run.get("SQ_INSTS_SALU", 0.0) / eps, "lds_insts_per_episode": run.get("SQ_INSTS_LDS", 0.0) / eps,
            "issue_slot_frac": insts / slots if slots > 0 else None}
-    for v in ("heavy", "short", "lean", "coop"):      # a batch with replay episodes: the grids of the launch, measured one after the other
+    for v in ("heavy", "solo", "short", "lean", "coop"):      # a batch with replay episodes: the grids of the launch, measured one after the other
         if isinstance(run.get(v), dict) and "valu_busy" in run[v]:
             out[f"valu_busy_{v}_grid"] = run[v]["valu_busy"]
     return out
@@ -501,6 +501,10 @@ def main():
                                    + "; batch pass = rollout (grid step + tabular policy sampling) + batch policy update on the device; synthetic world "
                                      "S=130 settlements / G0=59 existing plant / P=200 coast points, seed 12345",
                        "episodes_per_gpu_per_batch": args.episodes, "replay_fraction": args.replay_fraction, "replay_hoist": bool(args.replay_hoist),
+                       # which kernel runs a long replay episode when every episode is executed on its own (csrc/eg_replay_solo.h)
+                       "per_episode_replay_kernel": ("k_rollout<0,2> (EIRGRID_REPLAY_SOLO=0: year by year, action by action)" if os.environ.get("EIRGRID_REPLAY_SOLO", "1")[:1] == "0"
+                                                     else "k_replay_solo (each replay episode's script, placements and yearly rows on its own wave; k_rollout<0,2> behind it for "
+                                                          "scripts that need a seeded draw)"),
                        "batches_timed": m["batches"], "episodes_failed": m["failed"],
                        "parallelism": f"episode-sharded dp{world_size}, policy resident on every GPU, one all-gather of {N_PACKET_BYTES} bytes per rank per update "
                                       "(integer statistics summed in the update kernel)",

@@ -19,11 +19,12 @@ import csv, glob, json, os, sys
 TIMED = 8
 
 
-VARIANTS = ("heavy", "short", "lean", "coop", "books", "bcast")
+VARIANTS = ("heavy", "short", "lean", "coop", "books", "bcast", "solo")
 
 
 def variant_of(name):      # k_rollout<helpers, kind>: kind 2 = long-replay (heavy-capable) variant, 1 = short-replay, 0 = lean
-    for key, v in (("k_replay_coop", "coop"), ("k_replay_books", "books"), ("k_replay_broadcast", "bcast")):      # the replay hoist's kernels
+    for key, v in (("k_replay_coop", "coop"), ("k_replay_books", "books"), ("k_replay_broadcast", "bcast"),      # the replay hoist's kernels
+                   ("k_replay_solo", "solo")):      # the per-episode replay kernel (k_rollout<.., 2> behind it then has nothing to do)
         if key in name: return v
     if "k_rollout" not in name: return None
     return "heavy" if ", 2>" in name else ("short" if ", 1>" in name else "lean")
@@ -63,8 +64,8 @@ def main():
         fa = sum(avg(f[v], "value_kb") for v in f); wa = sum(avg(w[v], "value_kb") for v in w)
         doc["configs"][wl] = dict(workload=wl, launches=max(len(f[v]) for v in f), fetch_size_kb_avg=fa, write_size_kb_avg=wa,
                                   hbm_bytes_per_launch=2 * fa * 1024 + wa * 1024,
-                                  kernel_ns=sum(avg(f[v], "dur_ns") for v in ("heavy", "short", "lean")),
-                                  kernel_ns_heavy=avg(f["heavy"], "dur_ns"), kernel_ns_short=avg(f["short"], "dur_ns"), kernel_ns_lean=avg(f["lean"], "dur_ns"),
+                                  kernel_ns=sum(avg(f[v], "dur_ns") for v in ("heavy", "short", "lean", "solo")),
+                                  kernel_ns_heavy=avg(f["heavy"], "dur_ns") + avg(f["solo"], "dur_ns"), kernel_ns_short=avg(f["short"], "dur_ns"), kernel_ns_lean=avg(f["lean"], "dur_ns"),
                                   kernel_ns_hoist=sum(avg(f[v], "dur_ns") for v in ("coop", "books", "bcast")),
                                   fetch_rows=f, write_rows=w)
     path = os.path.join(out_dir, f"{tag}_pmc_hbm_traffic.json")

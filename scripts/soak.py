@@ -31,6 +31,10 @@ engines["hoist"] = Engine(world, device=0); engines["hoist"].replay_hoist(True)
 os.environ["EIRGRID_COOP_FORCE"] = "1"
 engines["hoist_slow"] = Engine(world, device=0); engines["hoist_slow"].replay_hoist(True)
 del os.environ["EIRGRID_COOP_FORCE"]
+# the throughput kernels without k_replay_solo (eg_replay_solo.h: engine "0" runs long replay episodes through it): k_rollout<0,2> alone
+os.environ["EIRGRID_HELPER_WAVES"] = "0"; os.environ["EIRGRID_REPLAY_SOLO"] = "0"
+engines["classic"] = Engine(world, device=0)
+del os.environ["EIRGRID_HELPER_WAVES"]; del os.environ["EIRGRID_REPLAY_SOLO"]
 served = 0
 dev = Engine(world, device=0)
 tb = O.OracleTables(HostTables(world), len(world.existing_x))
@@ -65,7 +69,7 @@ for trial in range(trials):
     for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
         assert getattr(a, name).tobytes() == getattr(b, name).tobytes(), (trial, name)
         assert getattr(a, name).tobytes() == getattr(c, name).tobytes(), (trial, name, "field path vs exact scan")
-    for key in ("hoist", "hoist_slow"):
+    for key in ("hoist", "hoist_slow", "classic"):
         h = engines[key].rollout_batch(pol, seed, n, first_episode_index=first, replay_mask=mask)
         for name in ("status", "metrics", "yearly", "n_run", "n_def", "n_act", "n_gens", "n_offsets", "n_draws", "bytes_moved"):
             assert getattr(a, name).tobytes() == getattr(h, name).tobytes(), (trial, name, key)

@@ -17,18 +17,18 @@ from eirgrid_amd import _native as N
 doc["build_hash"] = N.lib().eg_build_hash().decode()      # the library the counters were taken on (bench.py checks it)
 for spec in specs:
     wl, d = spec.split(":")
-    per = {"heavy": {}, "short": {}, "lean": {}, "coop": {}, "books": {}, "bcast": {}}
+    per = {"heavy": {}, "short": {}, "lean": {}, "coop": {}, "books": {}, "bcast": {}, "solo": {}}
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             nm = r["Kernel_Name"]
-            hoist = [v for key, v in (("k_replay_coop", "coop"), ("k_replay_books", "books"), ("k_replay_broadcast", "bcast")) if key in nm]
+            hoist = [v for key, v in (("k_replay_coop", "coop"), ("k_replay_books", "books"), ("k_replay_broadcast", "bcast"), ("k_replay_solo", "solo")) if key in nm]
             if "k_rollout" not in nm and not hoist: continue
             v = hoist[0] if hoist else ("heavy" if ", 2>" in nm else ("short" if ", 1>" in nm else "lean"))      # k_rollout<helpers, kind>; the replay hoist's kernels
             e = per[v].setdefault(int(r["Dispatch_Id"]), {"grid": int(r["Grid_Size"])})
             e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             e["duration_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     run = {}
-    for v in ("heavy", "short", "lean", "coop", "books", "bcast"):
+    for v in ("heavy", "short", "lean", "coop", "books", "bcast", "solo"):
         ids = sorted(per[v])
         if not ids: continue
         grid = per[v][ids[-1]]["grid"]
@@ -41,7 +41,7 @@ for spec in specs:
     eps = int(wl.split("r")[0])      # ("16384r0.1", "16384r0.1grown", "16384r0.1grownhoist", "1024")
     run["episodes_per_launch"] = eps; run["clock_hz"] = 2.4e9
     run["valu_busy"] = run.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024 * run["duration_ns"] * 1e-9 * 2.4e9)
-    for v in ("heavy", "short", "lean", "coop", "books", "bcast"):
+    for v in ("heavy", "short", "lean", "coop", "books", "bcast", "solo"):
         if v in run: run[v]["valu_busy"] = run[v].get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (1024 * run[v]["duration_ns"] * 1e-9 * 2.4e9)
     doc["runs"][wl] = run
 out = os.path.join(out_dir, f"{tag}_sq_counters.json")
@@ -49,4 +49,4 @@ json.dump(doc, open(out, "w"), indent=1)
 for wl, r in doc["runs"].items():
     e = r["episodes_per_launch"]
     print(wl, {k: round(v / e) for k, v in r.items() if k.startswith("SQ_INSTS")}, "valu_busy", round(r["valu_busy"], 3), "kernel ms (serialised)", round(r["duration_ns"] * 1e-6, 3),
-          {v: (round(r[v]["valu_busy"], 3), round(r[v]["duration_ns"] * 1e-6, 3)) for v in ("heavy", "short", "lean") if v in r})
+          {v: (round(r[v]["valu_busy"], 3), round(r[v]["duration_ns"] * 1e-6, 3)) for v in ("heavy", "solo", "short", "lean") if v in r})
