@@ -16,7 +16,7 @@ python - <<PY
 import json
 for n in ("classic", "solo", "classic2", "solo2"):
     l = json.loads(open("$O/bench_%s.json" % n).read().strip().splitlines()[-1])
-    print(n, round(l["value"]), "eps/s", round(l["ms_per_batch"], 4), "ms/batch; hoisted", round(l["config2_replay_hoisted"]["value"]))
+    print(n, round(l["value"]), "eps/s", round(l["ms_per_batch"], 4), "ms/batch;", l["config"]["per_episode_replay_kernel"][:14])
 PY
 head -12 $O/kernel_stats.csv | cut -c1-200
 rm -rf $O/prof
