@@ -912,7 +912,11 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
   // factor table of the radius class: byte offset inside sl.dr16 (small-batch kernel) / inside the LDS block (sm.dr)
   const int table = kHelpers > 0 ? rc * (kD2Stride * 16) : throughput_table(info);
   const double size_factor = T.size_factor;
+#ifdef EG_PROBE_NO_GEN_LOOP      // diagnostic build only (profiles/r04_ab_notes.log r04u): the searches fold no generator — what the generator loops cost
+  const int ngen_s = 0;
+#else
   const int ngen_s = __builtin_amdgcn_readfirstlane(ngen);
+#endif
   constexpr int kChunks = (kCells + kWave - 1) / kWave;
   double best = 0.0, m03w = 0.0; int best_c = kCells;
   int first = 0;
