@@ -1715,6 +1715,20 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   }
   const uint32_t e = map_episode(emap, blockIdx.x);
   if (e >= n_episodes) return;
+  // The tail of a large launch.  A grid of several rounds of waves ends when its last-dispatched episodes do, and those run their last
+  // stretch on SIMDs that are emptying (a launch of 16 384 sampled episodes keeps 3.1 of its 4 wave slots per SIMD filled on average,
+  // profiles/r04_lean_occupancy.txt).  The episodes dispatched last therefore win issue arbitration over the older waves on their
+  // SIMD — which are about to end anyway —, in three steps of 640 workgroups: 16 384 episodes 1.028 -> 1.001 ms, 14 746: 0.942 -> 0.914
+  // (profiles/r04_ab_notes.log r04x).  Not for grids that are resident all at once.
+  if constexpr (kHelpers == 0) {
+    constexpr uint32_t kTailStep = 640u;
+    if (emap.count > 8192u) {
+      const uint32_t behind = emap.count - 1u - blockIdx.x;      // workgroups dispatched after this one
+      if (behind < kTailStep) __builtin_amdgcn_s_setprio(3);
+      else if (behind < 2u * kTailStep) __builtin_amdgcn_s_setprio(2);
+      else if (behind < 3u * kTailStep) __builtin_amdgcn_s_setprio(1);
+    }
+  }
   uint32_t search_seq = 0, year_seq = 0;      // commands to the helper wave share one sequence
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   if constexpr (kHelpers > 0) {   // waves 1..kHelpers serve the episode wave's placement searches (see helper_loop)
