@@ -19,17 +19,20 @@ from tests.test_gpu_replay_hoist import _full_script, _seeded
 pytestmark = pytest.mark.gpu
 
 
-def _pair(world):
+def _pair(world, pool=True):
     """(engine with the classic long-replay variant only, engine with k_replay_solo ahead of it); large-batch launch shape — the
-    small-batch kernel (helper waves) has no such kernel"""
+    small-batch kernel (helper waves) has no such kernel.  pool=False: no penalty-field pool (EIRGRID_HEAVY_SLOTS=0) — every search
+    of a long list is the exact scan"""
     os.environ["EIRGRID_HELPER_WAVES"] = "0"
+    if not pool:
+        os.environ["EIRGRID_HEAVY_SLOTS"] = "0"
     try:
         os.environ["EIRGRID_REPLAY_SOLO"] = "0"
         classic = Engine(world, device=0)
         os.environ["EIRGRID_REPLAY_SOLO"] = "1"
         solo = Engine(world, device=0)
     finally:
-        os.environ.pop("EIRGRID_REPLAY_SOLO", None); os.environ.pop("EIRGRID_HELPER_WAVES", None)
+        os.environ.pop("EIRGRID_REPLAY_SOLO", None); os.environ.pop("EIRGRID_HELPER_WAVES", None); os.environ.pop("EIRGRID_HEAVY_SLOTS", None)
     return classic, solo
 
 
@@ -127,3 +130,26 @@ def test_training_loops_with_and_without_the_solo_kernel(world):
             eng.close()
     assert states[0] == states[1]
     assert sum(len(l) for l in pol.lists(0)) > 96, "the loop has reached the long-replay variant"
+
+
+def test_other_options_another_world_and_no_field_pool(world):
+    """The run options that change what a replay writes (no energy sales, no yearly rows), another synthetic world, and engines without
+    a penalty-field pool (every search of a long list is place_search / place_exact_long): same bytes as the classic variant."""
+    from eirgrid_amd.world import synthetic_world
+    rng = np.random.default_rng(919)
+    other = synthetic_world(seed=0xE16D0003)
+    for wld, kwargs, pool in ((world, {"enable_energy_sales": False, "write_yearly": False}, True), (other, {}, True), (world, {}, False)):
+        classic, solo = _pair(wld, pool)
+        try:
+            for k, pol in enumerate((_full_script(rng, 6, [0, 4, 12, 7, 1], offsets_per_year=1), _full_script(rng, 26, [0, 4, 12, 7, 5, 13, 9], offsets_per_year=2))):
+                n = 48
+                mask = (np.arange(n) % 4 == 1).astype(np.uint8)
+                a = classic.rollout_batch(pol, 66 + k, n, replay_mask=mask, **kwargs)
+                b = solo.rollout_batch(pol, 66 + k, n, replay_mask=mask, **kwargs)
+                assert (a.status == 0).all()
+                for name in _ALL_FIELDS + ("n_chunks",):
+                    if name == "yearly" and not kwargs.get("write_yearly", True):
+                        continue
+                    assert _used(a, name).tobytes() == _used(b, name).tobytes(), (k, name, kwargs, pool)
+        finally:
+            classic.close(); solo.close()
