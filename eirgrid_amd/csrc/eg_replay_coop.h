@@ -14,9 +14,9 @@
 //      k_rollout's replay path statement for statement, minus the placement, the in-episode weight nudges (learning.rs:21-88,
 //      deficit.rs:82-135: they only touch the episode's private copy of the tables, which a replay never samples from and which is
 //      dropped at its end — Q5) and every aggregate but the three output class sums.
-//   2. THE PLACEMENTS (k_replay_coop, all four waves — one per SIMD of a CU, each with the SIMD's whole register file; the work of a
-//      search does not get shorter by spreading it over more waves than there are SIMDs to issue for them).  Serial by nature: a
-//      search sees every generator before it.  A search is an arg-max over all 2 601 candidate cells at once, eleven cells per lane:
+//   2. THE PLACEMENTS (k_replay_coop, all eight waves — two per SIMD of a CU: with four, one per SIMD, a placement took 2 545 cycles; a
+//      second wave per SIMD issues into the first one's waits; sixteen are slower again, profiles/r04_ab_notes.log r04z).  Serial by nature: a
+//      search sees every generator before it.  A search is an arg-max over all 2 601 candidate cells at once, six cells per lane:
 //      the product of the penalty factors of every generator placed so far is kept per radius class and cell in LDS (field[6][2624]
 //      f64, 126 KB of the CU's 160 KB; updated for the new generator by one lane per (class, di, dj) entry of the host's list), the
 //      year's unpenalised scores (tab::cbase) sit in registers, so approx(c) = base(c) * field[c] is a read and a multiplication per
@@ -26,7 +26,7 @@
 //      its cell is asked for.  Otherwise every cell within 2^-30 of the exact maximum of the approximate scores is evaluated EXACTLY
 //      — te times the factors in list order, a candidate a wave (exact_product_chain's arithmetic) — and the first maximum in cell
 //      order wins; subnormal ranges, more than 64 such cells or no positive score fall back to the exact scan of all cells (every
-//      lane folds the whole list for its eleven cells).  The winner is metal_location_search.rs:110-176's, bit for bit, as with
+//      lane folds the whole list for its six cells).  The winner is metal_location_search.rs:110-176's, bit for bit, as with
 //      place_search / place_heavy.
 //   3. THE YEARLY ROWS (k_replay_books, a wave a year).  Every aggregate of a year is a sum over the generators / offsets in list
 //      order (map_handler.rs:829-965): started from the existing-plant prefix at the year's start and continued with every addition,
@@ -40,11 +40,14 @@
 // any case — run the episodes as before: they return at once only when HoistInfo::served_seq carries their batch's sequence number.
 #pragma once
 
+#ifndef EG_COOP_WAVES
+#define EG_COOP_WAVES 8
+#endif
 namespace coop {
 
-constexpr int kWaves = 4, kThreads = kWaves * kWave;
-constexpr int kPer = (kCells + kThreads - 1) / kThreads;      // candidate cells per lane: 11 (cell = tid + 256 k)
-constexpr int kEnt = 1024 / kThreads;                         // entries of the field update per lane: 4
+constexpr int kWaves = EG_COOP_WAVES, kThreads = kWaves * kWave;
+constexpr int kPer = (kCells + kThreads - 1) / kThreads;      // candidate cells per lane: 6 (cell = tid + 512 k)
+constexpr int kEnt = 1024 / kThreads;                         // entries of the field update per lane: 2
 constexpr double kKeepCoop = 1.0 - 0x1p-30;
 constexpr int kVariants = 8;                                  // (radius class, marine) pairs whose scores a lane keeps in registers — the reference's
                                                               // fifteen types make eight; a world with more is not hoisted (eg_api.cpp)
@@ -113,7 +116,7 @@ __device__ __forceinline__ double exact_chain(int off, int cap, int ngen, double
 
 // ---- a search, fast path: this lane's cells against the field, the exchange, the decision.  `b`: the lane's unpenalised scores of the
 //      (year, variant) — registers; returns the winning cell, or -2: several cells within reach of the maximum / nothing placeable (the
-//      caller takes the slow path).  Called by all four waves; every lane returns the same value. ----
+//      caller takes the slow path).  Called by all waves; every lane returns the same value. ----
 __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ int scan_fast(const double (&b)[kPer], int rc, int tid, int lane, int wave EG_CS_ARGS) {
   const char* f0 = reinterpret_cast<const char*>(sc.field) + (rc * kFieldStride + tid) * 8;
