@@ -150,6 +150,14 @@ struct State { double net, opinion, balance, cost; };   // ActionResult, simulat
 __device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
 __device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
 __device__ __forceinline__ double dabs(double a) { return a < 0.0 ? -a : a; }
+// v_max_f64 / v_min_f64 as such: from `a > b ? a : b` the compiler makes a compare and two selects (it may not assume that there are no
+// NaNs and that the sign of a zero does not matter).  Only where neither can occur: weights and scores (positive, finite), and
+// max(|x|, 1.0) (at least 1.0 whatever the sign of a zero x).
+__device__ __forceinline__ double vmax64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmin64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double vmax64_u(double a, double uniform_b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(uniform_b)); return r; }
+__device__ __forceinline__ double vmin64_u(double a, double uniform_b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(uniform_b)); return r; }
+__device__ __forceinline__ double max_abs_one(double a) { double r; asm("v_max_f64 %0, |%1|, 1.0" : "=v"(r) : "v"(a)); return r; }      // max(|a|, 1.0)
 __device__ __forceinline__ uint32_t rotl32(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
 
 #define EG_QR(a, b, c, d)                                                         \
@@ -257,10 +265,10 @@ __device__ __forceinline__ State state_of(const Agg& a) {   // simulation.rs:122
   return s;
 }
 __device__ double evaluate_impact(const State& cur, const State& nxt) {   // scoring.rs:46-85 (mode None)
-  if (cur.net > 0.0) return (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0);
+  if (cur.net > 0.0) return (cur.net - nxt.net) / max_abs_one(cur.net);
   double cost_change = nxt.cost - cur.cost;
-  double cost_improvement = -cost_change / dmax(dabs(cur.cost), 1.0);
-  double opinion_improvement = (nxt.opinion - cur.opinion) / dmax(dabs(cur.opinion), 1.0);
+  double cost_improvement = -cost_change / max_abs_one(cur.cost);
+  double opinion_improvement = (nxt.opinion - cur.opinion) / max_abs_one(cur.opinion);
   double cost_weight = cur.cost > kMaxCost * 8.0 ? 0.8 : 0.5;
   double opinion_weight = 1.0 - cost_weight;
   return cost_improvement * cost_weight + opinion_improvement * opinion_weight;
@@ -377,6 +385,9 @@ __device__ __forceinline__ double wave_prefix_sum_f64(double x) {
 // Not inlined (four call sites; inlined, the rarely-run sequential part costs the episode loop its registers).  The table
 // is given by its byte offset inside the workgroup's LDS block so that it is read with LDS instructions.
 __device__ __noinline__ int weighted_pick(int table_offset, int n, double u, int lane) {
+#if defined(EG_PROBE_SKIP) && EG_PROBE_SKIP == 5
+  if (true) return (int)(u * (double)n);
+#endif
   const double* table = reinterpret_cast<const double*>(reinterpret_cast<const char*>(&sm) + table_offset);
   const double w = lane < n ? table[lane] : 0.0;
   const double P = wave_prefix_sum_f64(w);
@@ -582,12 +593,13 @@ template <bool kLatency>
 __device__ __forceinline__ ChunkBest chunk_reduce(double s, int cell, double m03) {
   ChunkBest b;
   // Scores are not negative, so their order is the order of their bit patterns.  Almost always a single lane holds the
-  // largest high word: that lane is the winner and nothing else has to be reduced (small-batch kernel: fewer
-  // instructions on the critical path; the throughput kernel keeps the branch-free form).
+  // largest high word: that lane is the winner and nothing else has to be reduced.  (Small-batch kernel: fewer instructions on
+  // the critical path.  Throughput kernels: fewer vector instructions — they are bound by vector issue; 16 384 sampled episodes
+  // 1.002 -> 0.982 ms, profiles/r04_ab_notes.log r04za; the branch-free form had measured equal before the kernel was that tight.)
   const unsigned hi = (unsigned)__double2hiint(s);
   const unsigned mh = wave_max_u32(hi);
   const unsigned long long top = __ballot(hi == mh);
-  if (kLatency && __popcll(top) == 1) {
+  if (__popcll(top) == 1) {
     const int w = __ffsll((long long)top) - 1;
     b.score = readlane_f64(s, w); b.cell = __builtin_amdgcn_readlane(cell, w); b.m03 = readlane_f64(m03, w);
     return b;
@@ -1288,8 +1300,8 @@ __device__ __noinline__ int place_heavy(unsigned long long list_addr, unsigned l
       const double v = CB[j] * ap[j];                                                                                            \
       const double key = __hiloint2double(__double2hiint(v), (__double2loint(v) & ~63) | ((g_) * kGroup + j));                   \
       const bool larger = key > lm;                                                                                              \
-      l2 = dmax(l2, dmin(lm, key));                                                                                              \
-      lm = dmax(lm, key);                                                                                                        \
+      l2 = vmax64(l2, vmin64(lm, key));      /* (scores: not negative, finite) */                                                \
+      lm = vmax64(lm, key);                                                                                                      \
       lcell = larger ? CC[j] : lcell;                                                                                            \
     }                                                                                                                            \
     M = __hiloint2double((int)wave_max_u32((unsigned)__double2hiint(lm)), 0);      /* (scores are not negative: ordered like their bit patterns) */ \
@@ -1424,15 +1436,15 @@ __device__ __forceinline__ void nudge_after_repair(const DevSnapshot& S, int lan
   wave_sync();
   if (lane < EG_N_ACTIONS) {
     double v = SM_W[lane];
-    if (lane == action) v = dmin(dmax(v * adj_w, kMinWeight), kMaxWeight);
-    else if (combined < 0.0 && lane < kFirstOffset) v = dmin(v * boost, kMaxWeight);
-    if (combined < 0.0 && S.noop_boost && lane == kNothing) v = dmin(v * S.boost_noop, kMaxWeight);
+    if (lane == action) v = vmin64_u(vmax64_u(v * adj_w, kMinWeight), kMaxWeight);      // (weights: positive, finite)
+    else if (combined < 0.0 && lane < kFirstOffset) v = vmin64_u(v * boost, kMaxWeight);
+    if (combined < 0.0 && S.noop_boost && lane == kNothing) v = vmin64_u(v * S.boost_noop, kMaxWeight);
     SM_W[lane] = v;
   }
   if (slot >= 0 && lane < EG_N_DEFICIT) {
     double v = SM_DW[lane];
-    if (lane == slot) v = dmin(dmax(v * adj_d, kMinWeight), kMaxWeight);
-    else if (d_improvement < 0.0 && lane < 14) v = dmin(v * boost, kMaxWeight);
+    if (lane == slot) v = vmin64_u(vmax64_u(v * adj_d, kMinWeight), kMaxWeight);
+    else if (d_improvement < 0.0 && lane < 14) v = vmin64_u(v * boost, kMaxWeight);
     SM_DW[lane] = v;
   }
   wave_sync();
@@ -1850,7 +1862,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         ys.co2 = sm.ysum[4]; ys.tg = sm.ysum[5]; ys.ig = sm.ysum[6]; ys.sg = sm.ysum[7]; ys.opcnt = sm.ysum_opcnt;
       } else {
         ys = year_sums_init_current();
+#if !defined(EG_PROBE_SKIP) || EG_PROBE_SKIP != 3
         year_fold<kHeavy>(T, lane, yi, ngen_s, noff_s, carry, terms, ys, tail);
+#endif
       }
       a.gcost = ys.gcost; a.optot = ys.optot; a.offs = ys.offs; a.ocost = ys.ocost; a.opcnt = ys.opcnt;
       if (carry) { a.co2 = sm.yend[2]; a.tg = sm.yend[3]; a.ig = sm.yend[4]; a.sg = sm.yend[5]; }
@@ -2134,16 +2148,20 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         ep.def_pos += 1; ep.n_def_y += 1; ep.run_pos += 1; ep.n_run_y += 1;
         EG_MARKG(22);
         const State nxt = state_of(a);
+#if defined(EG_PROBE_SKIP) && EG_PROBE_SKIP == 2      // diagnostic builds only (profiles/r04_ab_notes.log r04zb): what a piece costs in vector instructions
+        remaining = -dmin(nxt.balance, 0.0); cur = nxt;
+        if (true) continue;
+#endif
         // evaluate_action_impact (scoring.rs:46-85) and the emission / cost terms of simulation.rs:420-452 divide the same
         // differences by the same denominators: each quotient is formed once
         const bool net_positive = cur.net > 0.0;
         double q_net = 0.0, q_cost = 0.0;
-        if (net_positive || nxt.net < cur.net) q_net = (cur.net - nxt.net) / dmax(dabs(cur.net), 1.0);
-        if (!net_positive || nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; q_cost = -cost_change / dmax(dabs(cur.cost), 1.0); }
+        if (net_positive || nxt.net < cur.net) q_net = (cur.net - nxt.net) / max_abs_one(cur.net);
+        if (!net_positive || nxt.net < 1000.0) { const double cost_change = nxt.cost - cur.cost; q_cost = -cost_change / max_abs_one(cur.cost); }
         double overall;
         if (net_positive) overall = q_net;
         else {
-          const double opinion_improvement = (nxt.opinion - cur.opinion) / dmax(dabs(cur.opinion), 1.0);
+          const double opinion_improvement = (nxt.opinion - cur.opinion) / max_abs_one(cur.opinion);
           const double cost_weight = cur.cost > kMaxCost * 8.0 ? 0.8 : 0.5;
           overall = q_cost * cost_weight + opinion_improvement * (1.0 - cost_weight);
         }
@@ -2151,7 +2169,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         const double ci = nxt.net < 1000.0 ? q_cost : 0.0;
         const double oi = nxt.cost < kMaxCost * 8.0 ? (nxt.opinion - cur.opinion) / dmax(1.0 - cur.opinion, 0.1) : 0.0;
         const double combined = overall * 0.7 + em * 0.15 + ci * 0.1 + oi * 0.05;
+#if !defined(EG_PROBE_SKIP) || EG_PROBE_SKIP != 1
         nudge_after_repair(S, lane, action, combined, overall * 0.5);
+#endif
         tot.scaled_valid = false;
         remaining = -dmin(nxt.balance, 0.0);
         cur = nxt;
@@ -2179,6 +2199,9 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
 
     // ---- yearly metrics (metrics_calculation.rs:32-175) ----
     EG_MARKG(25);
+#if defined(EG_PROBE_SKIP) && EG_PROBE_SKIP == 4
+    if (true) continue;
+#endif
     const State s = state_of(a);
     const double gen = (a.tg + a.ig) + a.sg;
     const double credit = s.net >= 0.0 ? 0.0 : (-s.net) * sm.pol[snap::kPolYear + 8];
