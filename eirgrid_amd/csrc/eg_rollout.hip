@@ -432,20 +432,27 @@ struct PrefixCache { double product; int key; int count; };      // key: year <<
 // The packed coordinates of 64 generators are staged in LDS once and come back four at a time as ONE broadcast 128-bit
 // read (instead of a readlane and a lane-index add each); per generator that leaves a packed subtract, the dot product,
 // the cap, the address, the table read and the multiply.
-__device__ __forceinline__ double chunk_product(int table, int lane, int k0, int ngen_s, double s_init, int cell, int stage) {
+// `row0_kept` (lean / short-replay kernels): staging row 0 is kept up to date by the episode — a generator's packed coordinates are
+// appended to it when the generator is placed (k_rollout), its other entries stay padding — so the first 64 generators need no
+// staging at all: a chunk re-staged the same list, cell -> (i, j) division included, ~15 vector instructions, 95 times an episode.
+// Blocks beyond the first 64 are staged in row 1 (the helper wave's, unused in those kernels).
+__device__ __forceinline__ double chunk_product(int table, int lane, int k0, int ngen_s, double s_init, int cell, int stage, bool row0_kept = false) {
   const int ci = cell / kGrid, cj = cell - ci * kGrid;
   double s = s_init;
   const short2v cpk = {(short)ci, (short)cj};
   const int dr_off = table & 0xFFFF, cap = table >> 16;   // throughput_table(): the class's factors inside the LDS block, and where they end
-  int* row = sm.gstage[stage];
-  const int4* row4 = reinterpret_cast<const int4*>(row);
   const int k0_s = __builtin_amdgcn_readfirstlane(k0);           // uniform (it comes out of a per-wave cache): scalar loop control
   for (int gb = k0_s; gb < ngen_s; gb += kWave) {                 // generators in list order
-    // Lanes beyond the list hold a generator far off the grid: its squared distance caps at 144, where the table is 1.0.
-    const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
-    const int mi = mine / kGrid;
-    const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
-    row[lane] = mp;
+    const bool kept = row0_kept && gb == 0;
+    int* row = sm.gstage[row0_kept && gb > 0 ? 1 : stage];
+    const int4* row4 = reinterpret_cast<const int4*>(row);
+    if (!kept) {
+      // Lanes beyond the list hold a generator far off the grid: its squared distance caps at 144, where the table is 1.0.
+      const int mine = gb + lane < ngen_s ? (int)(sm.gcell[gb + lane] & 0xFFF) : -1;
+      const int mi = mine / kGrid;
+      const int mp = mine < 0 ? (int)0xC000C000 : (mi | ((mine - mi * kGrid) << 16));   // (gi, gj) as two int16
+      row[lane] = mp;
+    }
     asm volatile("" ::: "memory");      // LDS executes a wave's accesses in program order: only the compiler must keep it
     const int cnt = ngen_s - gb < kWave ? ngen_s - gb : kWave;
     const int groups = (cnt + 3) >> 2;
@@ -567,10 +574,10 @@ __device__ __forceinline__ double chunk_product_latency(int class_off, int k0, i
 // coordinates); otherwise the throughput kernel (`table` = throughput_table() of the type, `cell`).
 template <bool kLatency>
 __device__ __forceinline__ double chunk_score(int table, double size_factor, int lane, int ngen_s, int r, double te,
-                                              double cf, int cell, int xy4) {
+                                              double cf, int cell, int xy4, bool row0_kept = false) {
   double p;
   if constexpr (kLatency) p = chunk_product_latency<false>(table, 0, ngen_s, te, xy4);
-  else p = chunk_product(table, lane, 0, ngen_s, te, cell, 0);
+  else p = chunk_product(table, lane, 0, ngen_s, te, cell, 0, row0_kept);
   const double s = (p * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
@@ -914,7 +921,7 @@ __device__ __forceinline__ void helper_loop(const DevTables& T, int lane, int h)
 
 // `between` is called once the candidate records are requested (and, in the small-batch kernel, the helper has its
 // command): whatever the caller has to do before it needs the result goes there and runs under the records' latency.
-template <int kHelpers, class Between>
+template <int kHelpers, bool kRow0Kept = false, class Between>
 __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi, int type, int ngen, double* best_score,
                                             double* best_m03, PrefixCache& cache0, Between&& between, int& nchunks,
                                             uint32_t* seq = nullptr, unsigned long long* stamps = nullptr) {
@@ -1003,7 +1010,7 @@ __device__ __forceinline__ int place_search(const DevTables& T, int lane, int yi
     // the single-wave kernel keeps the products of chunks 0 and 1, the episode wave of the helper kernel that of chunk 0
     // (the kept products are used by the small-batch kernel only: in the throughput kernel the extra live registers cost
     //  more than the shorter loops give back)
-    const double s = chunk_score<(kHelpers > 0)>(table, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur, xy_cur);
+    const double s = chunk_score<(kHelpers > 0)>(table, size_factor, lane, ngen_s, r, te_cur, cf_cur, cell_cur, xy_cur, kRow0Kept);
 #ifdef EG_STAMPS
     const unsigned long long tg1 = __builtin_readcyclecounter();
     if (stamps) stamps[9] += tg1 - tg0;
@@ -1780,6 +1787,7 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
   if (kHeavy && lane < 8) sm.hdbg[lane >> 2][lane & 3] = 0ull;
 #endif
   load_static_tables(T, lane, kHelpers == 0 || kHeavy);      // (the heavy variant's field update reads sm.dr / sl.dr16)
+  if constexpr (kHelpers == 0 && !kHeavy) sm.gstage[0][lane] = (int)0xC000C000;      // the kept staging row starts as padding (chunk_product)
   // bit y: the existing-plant prefix sums of year y equal those of year y-1, so last year's end-of-year class sums carry over
   const uint32_t carry_mask = (uint32_t)__ballot(lane > 0 && lane < EG_YEARS && T.pre_co2()[lane] == T.pre_co2()[lane - 1] &&
                                                  T.pre_tg()[lane] == T.pre_tg()[lane - 1] && T.pre_ig()[lane] == T.pre_ig()[lane - 1] &&
@@ -2068,10 +2076,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
         }
         if (!placed) {
 #ifdef EG_STAMPS
-          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq, stamps));
+          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers, (kHelpers == 0 && !kHeavy)>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq, stamps));
           stamps[11] += 1;
 #else
-          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq));
+          cell = __builtin_amdgcn_readfirstlane(place_search<kHelpers, (kHelpers == 0 && !kHeavy)>(T, lane, yi, t, ep.ngen, nullptr, &m03v, prefix_cache0, between, ep.chunks, &search_seq));
 #endif
         }
         EG_T1(1);
@@ -2109,6 +2117,10 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
           if (!kHeavy || ep.ngen < kLdsGens) {
             sm.gcell[ep.ngen] = (uint16_t)(cell | (t << 12));
             sm.gbm[ep.ngen] = (uint8_t)(yi | (m << 5));
+          }
+          if constexpr (kHelpers == 0 && !kHeavy) if (ep.ngen < kWave) {      // the searches' staging row, kept (chunk_product)
+            const int gi = cell / kGrid;
+            sm.gstage[0][ep.ngen] = gi | ((cell - gi * kGrid) << 16);
           }
           gen_cell[ep.ngen] = (uint16_t)cell;
           gen_pack[ep.ngen] = (uint16_t)(t | (yi << 4) | (m << 9));
