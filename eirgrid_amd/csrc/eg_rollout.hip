@@ -436,10 +436,11 @@ struct PrefixCache { double product; int key; int count; };      // key: year <<
 // appended to it when the generator is placed (k_rollout), its other entries stay padding — so the first 64 generators need no
 // staging at all: a chunk re-staged the same list, cell -> (i, j) division included, ~15 vector instructions, 95 times an episode.
 // Blocks beyond the first 64 are staged in row 1 (the helper wave's, unused in those kernels).
-__device__ __forceinline__ double chunk_product(int table, int lane, int k0, int ngen_s, double s_init, int cell, int stage, bool row0_kept = false) {
-  const int ci = cell / kGrid, cj = cell - ci * kGrid;
+// `xy4`: the candidate's packed coordinates times four (PsRec::pad, as the small-batch kernel uses them): a packed shift gives (ci, cj)
+// where dividing the cell by the grid's width took eight instructions per chunk.
+__device__ __forceinline__ double chunk_product(int table, int lane, int k0, int ngen_s, double s_init, int xy4, int stage, bool row0_kept = false) {
   double s = s_init;
-  const short2v cpk = {(short)ci, (short)cj};
+  const short2v cpk = __builtin_bit_cast(short2v, xy4) >> (short)2;      // (4 ci, 4 cj) -> (ci, cj): both halves are small and not negative
   const int dr_off = table & 0xFFFF, cap = table >> 16;   // throughput_table(): the class's factors inside the LDS block, and where they end
   const int k0_s = __builtin_amdgcn_readfirstlane(k0);           // uniform (it comes out of a per-wave cache): scalar loop control
   for (int gb = k0_s; gb < ngen_s; gb += kWave) {                 // generators in list order
@@ -577,7 +578,7 @@ __device__ __forceinline__ double chunk_score(int table, double size_factor, int
                                               double cf, int cell, int xy4, bool row0_kept = false) {
   double p;
   if constexpr (kLatency) p = chunk_product_latency<false>(table, 0, ngen_s, te, xy4);
-  else p = chunk_product(table, lane, 0, ngen_s, te, cell, 0, row0_kept);
+  else p = chunk_product(table, lane, 0, ngen_s, te, xy4, 0, row0_kept);
   const double s = (p * cf) * size_factor;
   return r < kCells ? s : 0.0;
 }
@@ -588,7 +589,7 @@ __device__ __forceinline__ double chunk_score(int table, double size_factor, int
   double s = te; int k0 = 0;
   if (cache.key == key && cache.count <= ngen_s) { s = cache.product; k0 = cache.count; }
   if constexpr (kLatency) s = stage ? chunk_product_latency<true>(table, k0, ngen_s, s, xy4) : chunk_product_latency<false>(table, k0, ngen_s, s, xy4);
-  else s = chunk_product(table, lane, k0, ngen_s, s, cell, stage);
+  else s = chunk_product(table, lane, k0, ngen_s, s, xy4, stage);
   cache.product = s; cache.key = key; cache.count = ngen_s;
   s = (s * cf) * size_factor;
   return r < kCells ? s : 0.0;
