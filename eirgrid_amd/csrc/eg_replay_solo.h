@@ -40,6 +40,39 @@ struct Lists {
 };
 static_assert(snap::kPolRow * 8 >= 60 * 4, "the script's lengths fit the policy row block");
 
+// The field update with the lane's list entries made ready once per class set (k_rollout's heavy_add_body decodes its entries — offsets,
+// class, the factor's place in the table — for every generator again: ~20 instructions an entry on the episode's serial path; here an
+// entry costs the bounds test, the address, the read-multiply-write).  The first eight entries per lane (the list of up to three or
+// four radius classes); lists that are longer go on through heavy_add_body.
+constexpr int kEnt = 8;
+struct Entries { int base[kEnt], delta[kEnt], dd[kEnt]; double fac[kEnt]; };      // class's first cell, di * 51 + dj, di | dj << 16, d/R
+__device__ __forceinline__ void load_entries(Entries& E, int lane) {      // from sh2.box: the episode's list as k_rollout keeps it (8 entries a lane)
+#pragma unroll
+  for (int k = 0; k < kEnt; ++k) {
+    const uint32_t en = sh2.box[k * kWave + lane];      // di + 16 | (dj + 16) << 5 | place in sm.dr << 10 | class << 19
+    const int rc = (int)(en >> 19), di = (int)(en & 31u) - 16, dj = (int)((en >> 5) & 31u) - 16;
+    E.base[k] = rc * kFieldStride; E.delta[k] = di * kGrid + dj; E.dd[k] = (di & 0xFFFF) | (int)((unsigned)dj << 16);
+    E.fac[k] = factor_by_q<false>(rc, (int)offsetof(Smem, dr), (int)((en >> 10) & 511u));
+  }
+}
+// field[class][cell + (di, dj)] *= d/R for the lane's first `n` entries (4 or 8; uniform).  No control flow per entry: an entry that
+// falls off the grid goes to its class's spare entry (never read), padding entries multiply by exactly 1.0 (heavy_add_body's rules).
+template <int kN>
+__device__ __forceinline__ void field_add(unsigned long long field_addr, const Entries& E, int cell) {
+  const GlobalF64 base = (GlobalF64)field_addr;
+  const int gi = cell / kGrid, gj = cell - gi * kGrid;
+  double val[kN]; int off[kN];
+#pragma unroll
+  for (int k = 0; k < kN; ++k) {
+    const int ci = gi + (int)(short)(E.dd[k] & 0xFFFF), cj = gj + (E.dd[k] >> 16);
+    const bool inside = (unsigned)ci < (unsigned)kGrid && (unsigned)cj < (unsigned)kGrid;
+    off[k] = E.base[k] + (inside ? cell + E.delta[k] : kCells);
+    val[k] = field_load(base + off[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < kN; ++k) base[off[k]] = val[k] * E.fac[k];
+}
+
 }  // namespace solo
 
 __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables T, DevSnapshot S_in, DevOut O, unsigned long long first_index, uint32_t n_episodes,
@@ -85,6 +118,9 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
   PrefixCache prefix_cache0 = {0.0, -1, 0};
   uint32_t search_seq = 0;
   int pk_block = 0;
+  solo::Entries E;
+#pragma unroll
+  for (int k = 0; k < solo::kEnt; ++k) { E.base[k] = 0; E.delta[k] = 0; E.dd[k] = 0; E.fac[k] = 1.0; }
   for (int g = 0; g < n_gens; ++g) {
     if ((g & (kWave - 1)) == 0) pk_block = g + lane < n_gens ? tail_u16(tail.gen_pack, g + lane) : 0;      // 64 pack words, one per lane
     const int pk = __builtin_amdgcn_readlane(pk_block, g & (kWave - 1));
@@ -109,6 +145,7 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
 #pragma unroll
           for (int k = 0; k < kBoxLds / kWave; ++k) sh2.box[k * kWave + lane] = T.hv_lists()[ep.heavy_classes * 1024 + k * kWave + lane];
           wave_sync();
+          solo::load_entries(E, lane);      // the lane's entries, ready for every field update until the next class joins
         }
         const size_t yv = (size_t)(yi * kMaxVariants + hv) * kPsStride, yc = (size_t)(yi * kMaxVariants + hv) * kPcStride;
         const int hr = place_heavy<false>((unsigned long long)(T.ps() + yv), (unsigned long long)(T.pbase() + yc), (unsigned long long)(T.pcell() + yc), class_addr,
@@ -130,8 +167,8 @@ __global__ void __launch_bounds__(kWave, EG_HEAVY_WAVES) k_replay_solo(DevTables
       const unsigned long long field_addr = (unsigned long long)T.heavy + (unsigned long long)ep.heavy * ((unsigned long long)(kRadiusClasses * kFieldStride) * 8ull);
       ep.chunks += 2 * ep.heavy_quads;
       const unsigned long long hv_list = (unsigned long long)(T.hv_lists() + ep.heavy_classes * 1024);
-      if (ep.heavy_quads == 1) heavy_add_body<false, 4>(field_addr, hv_list, lane, cell, 0);
-      else heavy_add_body<false, 8>(field_addr, hv_list, lane, cell, 0);
+      if (ep.heavy_quads == 1) solo::field_add<4>(field_addr, E, cell);
+      else solo::field_add<8>(field_addr, E, cell);
       if (ep.heavy_quads == 3) heavy_add_body<false, 4>(field_addr, hv_list, lane, cell, 8);
       else if (ep.heavy_quads >= 4) heavy_add_body<false, 8>(field_addr, hv_list, lane, cell, 8);
     }
