@@ -1903,9 +1903,15 @@ __global__ void __launch_bounds__(kWave * (1 + kHelpers), kKind == kReplayLong ?
       rep1 = kWave + lane < rep_n ? (int)S.best_actions()[rep_lo + kWave + lane] : 0;
       repd0 = lane < repd_n ? (int)S.bestd_actions()[repd_lo + lane] : 0;
     }
-    const State year_start = state_of(a);
+    // (the state at the start of the year is only read by the repair loop — most years have no deficit: its division waits for one)
+    State year_start;
+    year_start.balance = ((a.tg + a.ig) + a.sg) - a.usage;      // state_of(a).balance
+    year_start.net = 0.0; year_start.opinion = 0.0; year_start.cost = 0.0;
     int phase = year_start.balance < 0.0 ? 0 : 1;
-    if (lane == 0) { sm.ystate[0] = year_start.net; sm.ystate[1] = year_start.opinion; sm.ystate[2] = year_start.balance; sm.ystate[3] = year_start.cost; }
+    if (phase == 0) {
+      year_start = state_of(a);
+      if (lane == 0) { sm.ystate[0] = year_start.net; sm.ystate[1] = year_start.opinion; sm.ystate[2] = year_start.balance; sm.ystate[3] = year_start.cost; }
+    }
     double remaining = -year_start.balance;
     uint32_t attempts = 0, n_add = 0, k_add = 0;
     bool n_add_known = false;
