@@ -176,7 +176,7 @@ namespace snap {
 constexpr size_t kBestCap = 4096;     // best_actions can hold every replay-doubled year list
 // One 128-double block per year carries everything the episode wave loads into LDS at the start of that year:
 //   [0,61) main weights   [61] their table-order sum   [62] sum of the first 14 deficit weights   [63] sum of the count row
-//   [64,79) deficit weights   [79] stalled sampler: sum of the powered weights (written by k_stalled_tables)
+//   [64,79) deficit weights   [79] unused (was: the stalled sampler's sum of the powered weights; weighted_pick forms its own)
 //   [80,101) action-count weights (has_cw)
 //   [101,111) the world's scalars of that year (copied from the host tables at upload so that they need no LDS table of
 //             their own): existing-plant prefix of CO2 / dispatchable / intermittent / storage output / opinion total,

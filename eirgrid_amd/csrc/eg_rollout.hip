@@ -2402,12 +2402,8 @@ __device__ __forceinline__ void stalled_tables_year(uint8_t* snap_base, int y, i
     const double v = eg_detpow(mine, power);
     s_scaled[rank] = v; scaled[rank] = v; perm[rank] = (uint8_t)lane;
   }
-  wave_sync();
-  if (lane == 0) {
-    double t = 0.0;
-    for (int i = 0; i < EG_N_ACTIONS; ++i) t += s_scaled[i];
-    row[snap::kPolScaledTotal] = t;
-  }
+  // (the table-order sum of the powered weights is not kept: weighted_pick forms it from the table it is handed — a lane adding 61
+  //  LDS words one after the other was 4 of k_apply_update's microseconds in every stalled update; slot kPolScaledTotal stays 0)
 }
 __global__ void __launch_bounds__(kWave) k_stalled_tables(uint8_t* snap_base) {
   __shared__ double s_w[64], s_scaled[64];
