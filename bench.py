@@ -259,12 +259,13 @@ def roofline_object(workload, census, episodes, avg_kernel_s):
            "hbm_frac_measured": (tr_ok["bytes"] / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if tr_ok and avg_kernel_s > 0 else None,
            "traffic": tr_ok["bytes"] if tr_ok else None,
            "north_star_40pct_of_hbm": "not met and not a meaningful target on this path: an episode moves about 1 MB algorithmically (SURVEY finding 5, "
-                                      "§8(d)), the tables are L2 / Infinity-Cache resident, measured HBM use is 1-10 % of peak; the kernels are bound by "
+                                      "§8(d)), the tables are L2 / Infinity-Cache resident, measured HBM use is 2-13 % of peak; the kernels are bound by "
                                       "instruction issue on serial episode waves",
            "accounting": "achieved / frac / frac_requested / nominal_frac below = bytes by construction of the algorithm divided by kernel time: "
                          "frac bills the SURVEY §8(d) state terms (state that lives in LDS and never moves) plus the candidate records really requested; "
                          "frac_requested only what the code requests from the memory system; nominal_frac the SURVEY formula verbatim (it bills a "
-                         "20.8 KB score field per search that the branch-and-bound search never reads, and can exceed 1)",
+                         "20.8 KB score field per search that the branch-and-bound search never reads, and can exceed 1); frac itself passes 1 once "
+                         "the batch is fast enough — most of what it bills never leaves LDS — and says nothing about bandwidth: hbm_frac_measured does",
            "achieved": achieved, "peak": HBM_PEAK_GBS, "peak_measured": measured_peak(), "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS,
            "frac_requested": requested / avg_kernel_s / 1e9 / HBM_PEAK_GBS if avg_kernel_s > 0 else 0.0,
